@@ -1,0 +1,139 @@
+/*
+ * mirec -- C ABI of the MI355X (gfx950) recommender core.
+ *
+ * The reference has no FFI of its own: its numeric core is reached through the
+ * Python APIs of implicit 0.7.2 and lightfm 1.17.  Each entry point below is
+ * the device-side replacement of one of those calls and cites the reference
+ * call site it stands behind (paths relative to the reference repository).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name starts with `host_`;
+ *    the caller owns all memory, the library allocates nothing that outlives a
+ *    call and keeps no global state except a thread-local error string;
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no entry
+ *    point synchronises, except mirec_als_plan_build which returns counts to
+ *    the host;
+ *  - return value 0 = success, negative = error (MIREC_E_*); the message is
+ *    available from mirec_last_error() on the calling thread;
+ *  - factor matrices are row-major fp32 with row stride `f` floats, where `f`
+ *    must be a width the kernels are built for (mirec_factor_width(): multiples
+ *    of 32 up to 192 for the ALS kernels; multiples of 8 up to 192 for
+ *    scoring).  Callers with another width zero-pad columns: zero columns
+ *    change no result bit.
+ *  - CSR matrices: `indptr` int64[rows+1] (absolute offsets), `indices`
+ *    int32[nnz], `data` fp32[nnz].
+ */
+#ifndef MIREC_H
+#define MIREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIREC_OK 0
+#define MIREC_E_INVALID (-1)     /* bad argument (null pointer, size, unsupported width) */
+#define MIREC_E_WORKSPACE (-2)   /* workspace too small */
+#define MIREC_E_HIP (-3)         /* a HIP runtime call failed */
+#define MIREC_E_UNSUPPORTED (-4) /* valid request the kernels are not built for */
+
+typedef void* mirec_stream_t; /* hipStream_t */
+
+int mirec_version(void);
+const char* mirec_last_error(void);
+
+/* Smallest supported factor width >= f for the ALS kernels (`for_scoring` = 0)
+ * or for the scoring / top-K kernels (`for_scoring` = 1); -1 if f is too large. */
+int mirec_factor_width(int f, int for_scoring);
+
+/* ------------------------------------------------------------------------
+ * Shared Gram  G = Y^T Y + reg * I   (fp32 MFMA partials, fixed-order reduce).
+ * Replaces the `np.dot(Y.T, Y) + regularization * eye` that opens every
+ * half-sweep of implicit's `_least_squares_cg`, reached from
+ * als/als.py:174 and recommenders/als_recommender.py:136 (`model.fit`).
+ * `ws` must hold mirec_gram_workspace_bytes(n, f) bytes. */
+size_t mirec_gram_workspace_bytes(int64_t n, int f);
+int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, size_t ws_bytes,
+               mirec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * ALS half-sweep (implicit `_least_squares_cg`, cg_steps = 3 by default):
+ * for every row u in [row_begin, row_end) of the CSR matrix, warm-started from
+ * X[u]: build A_u = G + sum_k (|c_k|-1) y_k y_k^T and b_u = sum_{c_k>0} c_k y_k
+ * from the gathered rows y_k = Y[indices[k]], run `cg_steps` conjugate-gradient
+ * steps, store X[u].  Rows without entries are set to zero.
+ * Reference call sites: als/als.py:174, recommenders/als_recommender.py:136.
+ *
+ * A plan splits long rows into chunks of `chunk_nnz` stored entries so that
+ * heavy rows spread over many workgroups; it depends only on `indptr` and can
+ * be reused for every iteration of a fit.
+ *   nnz         stored entries in rows [row_begin, row_end)
+ *   plan        device buffer of mirec_als_plan_bytes(nrows, nnz, chunk_nnz)
+ *   chunk_nnz   in: requested chunk length, a multiple of 32 (0 = choose from
+ *               nnz); out: the length used
+ *   host_counts out: {number of chunks, number of split rows, number of
+ *               partial-result slots}
+ * mirec_als_plan_build synchronises `stream` before it returns.  The sweep
+ * takes the plan, `chunk_nnz` and `host_counts` exactly as the build left them
+ * and a workspace of mirec_als_sweep_workspace_bytes(host_counts, f) bytes. */
+size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk_nnz);
+int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_end, int64_t nnz, int f,
+                         void* plan, size_t plan_bytes, int32_t* chunk_nnz, int64_t host_counts[3],
+                         mirec_stream_t stream);
+size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[3], int f);
+int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
+                         int64_t row_end, int64_t nnz, float* X, const float* Y, const float* G, int f,
+                         int cg_steps, const void* plan, int32_t chunk_nnz, const int64_t host_counts[3],
+                         void* ws, size_t ws_bytes, mirec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * CSR transpose (`Ciu = Cui.T.tocsr()` inside implicit's fit; same call
+ * sites).  Output rows keep ascending column order.  `ws` must hold
+ * mirec_csr_transpose_workspace_bytes(rows, cols, nnz) bytes. */
+size_t mirec_csr_transpose_workspace_bytes(int64_t rows, int64_t cols, int64_t nnz);
+int mirec_csr_transpose(const int64_t* indptr, const int32_t* indices, const float* data, int64_t rows,
+                        int64_t cols, int64_t nnz, int64_t* t_indptr, int32_t* t_indices, float* t_data,
+                        void* ws, size_t ws_bytes, mirec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused score + top-K (implicit `recommend` / `similar_items` -> topk):
+ * for each of the nq query rows, score every item with the fp32 chain
+ * s = fma(q[f-1], y[f-1], ... fma(q[0], y[0], +0)), optionally divide by
+ * y_norm[item] and then q_norm[query], replace the entries listed in the
+ * query's mask row by -FLT_MAX, and keep the k best under the order
+ * (score descending, item index ascending).  The score matrix is never
+ * written to memory.  out_ids int32[nq,k], out_scores fp32[nq,k]; slots past
+ * the item count get id -1 and score -FLT_MAX.  k <= 224.
+ * Reference call sites: recommenders/als_recommender.py:181-186 (recommend,
+ * filter_already_liked_items=True), :237 (similar_items),
+ * hybrid_docker/inference.py:197 (argsort top-k, via mirec_lightfm_*).
+ * mask_indptr may be null (no filter); it is indexed by query row. */
+int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, int f, const int64_t* mask_indptr,
+               const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
+               float* out_scores, mirec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * LightFM representations (lightfm `compute_representation`, reached from
+ * `model.predict` at hybrid_docker/inference.py:159-165,188-194):
+ *   out[r, emb_col + j] = sum_k (w_k * scale) * E[indices[k], j]   (j < nc)
+ *   out[r, bias_col]    = sum_k (w_k * scale) * bias[indices[k]]
+ *   out[r, one_col]     = 1                      (skipped when one_col < 0)
+ * accumulated in stored order with one fma per entry; other columns of `out`
+ * (row stride `ld`) are left untouched.  With (bias_col, one_col, emb_col) =
+ * (0, 1, 2) for users and (1, 0, 2) for items, mirec_topk over the two outputs
+ * evaluates LightFM's score  (b_u + b_i) + sum_j u_j * i_j  in LightFM's order. */
+int mirec_lightfm_repr(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t rows,
+                       const float* E, const float* bias, float scale, int nc, float* out, int ld, int emb_col,
+                       int bias_col, int one_col, mirec_stream_t stream);
+
+/* LightFM.predict for explicit pairs (hybrid_docker/inference.py:159-165):
+ * urepr/irepr are [*, nc+1] with the bias in column nc. */
+int mirec_lightfm_predict(const float* urepr, const float* irepr, const int32_t* user_ids,
+                          const int32_t* item_ids, int64_t n, int nc, float* out, mirec_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIREC_H */

@@ -1,0 +1,101 @@
+"""The ``models/als@v1`` artefact layout (reference ``models/als@v1/manifest.yaml:1-13``).
+
+Writers in the reference disagree with each other: ``als/als.py:147-161,238-239``
+writes mappings without ``n_users``/``n_movies`` and the model as
+``{"model_state": ...}``, while the plugin's loader
+(``recommenders/als_recommender.py:56-103``) needs ``n_users``, ``n_movies``,
+``"model"`` and ``"most_popular_movies"``.  ``write_artifacts`` emits the
+superset, so either consumer can read the directory.
+"""
+
+from __future__ import annotations
+
+import json
+import pickle
+from pathlib import Path
+from typing import Any, Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+MANIFEST_CLASS_PATH = "movie_recommender_system_amd.recommender:ALSRecommender"
+
+
+def build_matrix(user_ids: Iterable, movie_ids: Iterable) -> Tuple[sp.csr_matrix, dict, dict, dict]:
+    """Binary interaction matrix from (user, movie) event pairs, as
+    ``build_matrix`` at ``als/als.py:107-123``: ids are compared as strings and
+    indexed in lexicographic order, repeated pairs collapse to one entry,
+    every stored value is 1.0 (fp32)."""
+    u = np.asarray([str(x) for x in user_ids], dtype=object)
+    m = np.asarray([str(x) for x in movie_ids], dtype=object)
+    if len(u) != len(m):
+        raise ValueError("user_ids and movie_ids differ in length")
+    users = sorted(set(u.tolist()))
+    movies = sorted(set(m.tolist()))
+    user_to_idx = {k: i for i, k in enumerate(users)}
+    movie_to_idx = {k: i for i, k in enumerate(movies)}
+    idx_to_movie = {i: k for k, i in movie_to_idx.items()}
+    rows = np.fromiter((user_to_idx[x] for x in u), dtype=np.int64, count=len(u))
+    cols = np.fromiter((movie_to_idx[x] for x in m), dtype=np.int64, count=len(m))
+    pairs = np.unique(rows * max(len(movies), 1) + cols)
+    rows, cols = pairs // max(len(movies), 1), pairs % max(len(movies), 1)
+    data = np.ones(len(pairs), dtype=np.float32)
+    matrix = sp.csr_matrix((data, (rows, cols)), shape=(len(users), len(movies)), dtype=np.float32)
+    return matrix, user_to_idx, movie_to_idx, idx_to_movie
+
+
+def popularity_order(matrix: sp.spmatrix, convention: str = "sort_then_reverse") -> np.ndarray:
+    """Item indices by descending interaction count (column sums of the
+    unscaled matrix).  The reference has two conventions that differ on ties:
+    ``argsort(sums)[::-1]`` (``recommenders/als_recommender.py:138-139``) and
+    ``argsort(-sums)`` (``als/als.py:175-176``)."""
+    sums = np.asarray(matrix.sum(axis=0)).ravel()
+    if convention == "sort_then_reverse":
+        return np.argsort(sums)[::-1]
+    if convention == "negate_then_sort":
+        return np.argsort(-sums)
+    raise ValueError(f"unknown convention {convention!r}")
+
+
+def mappings(user_to_idx: Dict[str, int], movie_to_idx: Dict[str, int]):
+    user_map = {"user_to_idx": dict(user_to_idx), "idx_to_user": {i: u for u, i in user_to_idx.items()},
+                "n_users": len(user_to_idx)}
+    movie_map = {"movie_to_idx": dict(movie_to_idx), "idx_to_movie": {i: m for m, i in movie_to_idx.items()},
+                 "n_movies": len(movie_to_idx)}
+    return user_map, movie_map
+
+
+def write_artifacts(model_dir, matrix: sp.csr_matrix, user_to_idx: Dict[str, int], movie_to_idx: Dict[str, int],
+                    model, most_popular: Optional[np.ndarray] = None, model_params: Optional[Dict[str, Any]] = None,
+                    version: str = "v1", name: str = "als", metadata: Optional[Dict[str, Any]] = None) -> Path:
+    """Write manifest.yaml, train_matrix.npz, the two mapping pickles,
+    als_model.pkl and dataset_stats.json into ``model_dir``."""
+    root = Path(model_dir)
+    root.mkdir(parents=True, exist_ok=True)
+    matrix = sp.csr_matrix(matrix).astype(np.float32)
+    sp.save_npz(root / "train_matrix.npz", matrix)
+    user_map, movie_map = mappings(user_to_idx, movie_to_idx)
+    with open(root / "user_mappings.pkl", "wb") as fh:
+        pickle.dump(user_map, fh)
+    with open(root / "movie_mappings.pkl", "wb") as fh:
+        pickle.dump(movie_map, fh)
+    if most_popular is None:
+        most_popular = popularity_order(matrix)
+    params = model_params or {k: getattr(model, k, None) for k in ("factors", "iterations", "regularization", "alpha")}
+    with open(root / "als_model.pkl", "wb") as fh:
+        pickle.dump({"model": model, "most_popular_movies": np.asarray(most_popular), "model_params": params,
+                     "model_state": model.__getstate__() if hasattr(model, "__getstate__") else None}, fh)
+    with open(root / "dataset_stats.json", "w", encoding="utf-8") as fh:
+        json.dump({"interactions": int(matrix.nnz), "users": len(user_to_idx), "movies": len(movie_to_idx)}, fh,
+                  indent=2)
+    manifest = {
+        "name": name, "version": version, "class_path": MANIFEST_CLASS_PATH,
+        "runtime": {"use_gpu": True},
+        "artefacts": {"model": "als_model.pkl", "user_mappings": "user_mappings.pkl",
+                      "movie_mappings": "movie_mappings.pkl", "train_matrix": "train_matrix.npz"},
+        "metadata": dict(metadata or {}),
+    }
+    import yaml
+    with open(root / "manifest.yaml", "w", encoding="utf-8") as fh:
+        yaml.safe_dump(manifest, fh, sort_keys=False)
+    return root

@@ -1,0 +1,530 @@
+// ALS half-sweep: per-row confidence-weighted Gram on the fp32 matrix cores,
+// then a warm-started conjugate-gradient solve (3 steps by default).
+//
+// Work unit = one "chunk": up to chunk_nnz stored entries of one CSR row.  A
+// workgroup of NT wavefronts (F = 32*NT factor columns) gathers the chunk's
+// factor rows 32 at a time through a double-buffered LDS tile and accumulates
+//     A += sum_k (|c_k|-1) y_k y_k^T      (v_mfma_f32_32x32x2_f32, wave w owns
+//                                          the 32-row band w of A)
+//     b += sum_k max(c_k,0) y_k
+// Rows that fit one chunk are finished in the same workgroup: A + G is written
+// to LDS (aliasing the gather tiles) and wave 0 runs the CG steps on it.  Rows
+// split over several chunks store their partial (A, b) to a workspace slot; a
+// second kernel sums the slots in chunk order (fixed, so results are
+// reproducible) and runs the same CG.
+#include "common.h"
+
+namespace mirec {
+
+constexpr int TR = 32;  // gathered rows per LDS tile
+
+// ---------------------------------------------------------------- plan -----
+// Device layout of a plan for `nrows` rows and at most `cap` chunks:
+//   int32 chunk_ptr[nrows+1]   exclusive scan of chunks per row
+//   int32 multi_ptr[nrows+1]   exclusive scan of (chunks per row > 1)
+//   int32 mslot_ptr[nrows+1]   exclusive scan of (chunks if > 1 else 0)
+//   int32 multi_row[nrows+1]   row of every split row (first n_multi used)
+//   int32 scan scratch
+//   int32 chunk_row[cap]       row of every chunk
+constexpr int SCAN_TILE = 2048;  // 256 threads x 8 items
+
+struct PlanLayout {
+    size_t chunk_ptr, multi_ptr, mslot_ptr, chunk_row, multi_row, scratch, total;
+    int64_t cap;
+    int scan_blocks;
+};
+
+static inline int32_t auto_chunk(int64_t nnz) {
+    int64_t c = (nnz / 16384 + 31) / 32 * 32;
+    if (c < 4096) c = 4096;
+    if (c > (1 << 20)) c = 1 << 20;
+    return (int32_t)c;
+}
+
+static inline PlanLayout plan_layout(int64_t nrows, int64_t nnz, int32_t chunk_nnz) {
+    PlanLayout L;
+    if (chunk_nnz <= 0) chunk_nnz = auto_chunk(nnz);
+    L.cap = nrows + nnz / chunk_nnz + 1;
+    const size_t arr = align_up((size_t)(nrows + 1) * 4, 256);
+    L.scan_blocks = (int)((nrows + 1 + SCAN_TILE - 1) / SCAN_TILE);
+    size_t off = 0;
+    // chunk_row comes last so that no other offset depends on the chunk capacity
+    L.chunk_ptr = off; off += arr;
+    L.multi_ptr = off; off += arr;
+    L.mslot_ptr = off; off += arr;
+    L.multi_row = off; off += arr;
+    L.scratch = off;   off += align_up((size_t)L.scan_blocks * 4, 256);
+    L.chunk_row = off; off += align_up((size_t)L.cap * 4, 256);
+    L.total = off;
+    return L;
+}
+
+__global__ void plan_count_kernel(const int64_t* __restrict__ indptr, int64_t row_begin, int64_t nrows,
+                                  int32_t chunk_nnz, int32_t* chunk_ptr, int32_t* multi_ptr, int32_t* mslot_ptr) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    int32_t nch = 0;
+    if (r < nrows) {
+        const int64_t nnz = indptr[row_begin + r + 1] - indptr[row_begin + r];
+        nch = nnz == 0 ? 1 : (int32_t)((nnz + chunk_nnz - 1) / chunk_nnz);
+    }
+    chunk_ptr[r] = nch;
+    multi_ptr[r] = nch > 1 ? 1 : 0;
+    mslot_ptr[r] = nch > 1 ? nch : 0;
+}
+
+// In-place exclusive scan of one 2048-element tile per block; block totals out.
+__global__ __launch_bounds__(256) void scan_tile_kernel(int32_t* data, int64_t n, int32_t* block_sums) {
+    __shared__ int32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)tid * 8;
+    int32_t v[8];
+    int32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int32_t t = (base + i < n) ? data[base + i] : 0;
+        v[i] = run;
+        run += t;
+    }
+    int32_t incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < wave) woff += wsum[i];
+        total += wsum[i];
+    }
+    const int32_t toff = woff + incl - run;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (base + i < n) data[base + i] = v[i] + toff;
+    if (tid == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void scan_sums_kernel(int32_t* block_sums, int nblk) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const int32_t t = block_sums[b];
+            block_sums[b] = run;
+            run += t;
+        }
+    }
+}
+
+__global__ void scan_add_kernel(int32_t* data, int64_t n, const int32_t* __restrict__ block_sums) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += block_sums[i / SCAN_TILE];
+}
+
+__global__ void plan_fill_kernel(int64_t nrows, const int32_t* __restrict__ chunk_ptr,
+                                 const int32_t* __restrict__ multi_ptr, int32_t* chunk_row, int32_t* multi_row) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int32_t c0 = chunk_ptr[r], c1 = chunk_ptr[r + 1];
+    for (int32_t c = c0; c < c1; ++c) chunk_row[c] = (int32_t)r;
+    if (c1 - c0 > 1) multi_row[multi_ptr[r]] = (int32_t)r;
+}
+
+static int exclusive_scan(int32_t* data, int64_t n, int32_t* scratch, hipStream_t stream) {
+    const int nblk = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(nblk), dim3(256), 0, stream, data, n, scratch);
+    MIREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(64), 0, stream, scratch, nblk);
+    MIREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n, scratch);
+    MIREC_LAUNCH_CHECK();
+    return MIREC_OK;
+}
+
+// ------------------------------------------------------------- kernels -----
+struct Staged {
+    float4 v[4];
+    float2 wc;
+};
+
+template <int NT>
+__device__ __forceinline__ void load_tile(Staged& st, const int32_t* __restrict__ indices,
+                                          const float* __restrict__ data, const float* __restrict__ Y, int64_t k0,
+                                          int64_t ke, int tid) {
+    constexpr int F = 32 * NT;
+    const int c4 = tid % (8 * NT);
+    const int rsub = tid / (8 * NT);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t k = k0 + p * 8 + rsub;
+        if (k < ke) {
+            const int32_t idx = indices[k];
+            st.v[p] = *reinterpret_cast<const float4*>(Y + (int64_t)idx * F + 4 * c4);
+        } else {
+            st.v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    st.wc = make_float2(0.f, 0.f);
+    if (tid < TR) {
+        const int64_t k = k0 + tid;
+        if (k < ke) {
+            const float c = data[k];
+            st.wc = make_float2(fabsf(c) - 1.f, c > 0.f ? c : 0.f);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void store_tile(const Staged& st, float* tile, float2* wts, int tid) {
+    constexpr int F = 32 * NT;
+    const int c4 = tid % (8 * NT);
+    const int rsub = tid / (8 * NT);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(tile + (p * 8 + rsub) * F + 4 * c4) = st.v[p];
+    if (tid < TR) wts[tid] = st.wc;
+}
+
+// out = A v for the symmetric LDS matrix A; lane holds columns lane + 64*m.
+template <int F>
+__device__ __forceinline__ void symv_wave(const float* A, float* vec, const float (&v)[(F + 63) / 64],
+                                          float (&out)[(F + 63) / 64], int lane) {
+    constexpr int NC = (F + 63) / 64;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int col = lane + 64 * m;
+        if (col < F) vec[col] = v[m];
+        out[m] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int colc[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) colc[m] = (lane + 64 * m < F) ? lane + 64 * m : F - 1;
+    for (int k = 0; k < F; k += 4) {
+        const float4 pk = *reinterpret_cast<const float4*>(vec + k);
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            out[m] = fmaf(A[(k + 0) * F + colc[m]], pk.x, out[m]);
+            out[m] = fmaf(A[(k + 1) * F + colc[m]], pk.y, out[m]);
+            out[m] = fmaf(A[(k + 2) * F + colc[m]], pk.z, out[m]);
+            out[m] = fmaf(A[(k + 3) * F + colc[m]], pk.w, out[m]);
+        }
+    }
+}
+
+// Conjugate-gradient steps of implicit's solver on the explicit system (A, b),
+// run by one wavefront; x is read from and written back to global memory.
+template <int F>
+__device__ void cg_solve_wave(const float* A, const float* b, float* vec, float* xg, int cg_steps, int lane) {
+    constexpr int NC = (F + 63) / 64;
+    float x[NC], r[NC], p[NC], Ap[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int col = lane + 64 * m;
+        x[m] = col < F ? xg[col] : 0.f;
+    }
+    symv_wave<F>(A, vec, x, Ap, lane);
+    float part = 0.f;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int col = lane + 64 * m;
+        r[m] = col < F ? b[col] - Ap[m] : 0.f;
+        p[m] = r[m];
+        part = fmaf(r[m], r[m], part);
+    }
+    float rsold = wave_sum(part);
+    if (rsold < 1e-20f) return;
+    for (int it = 0; it < cg_steps; ++it) {
+        symv_wave<F>(A, vec, p, Ap, lane);
+        part = 0.f;
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            if (lane + 64 * m >= F) Ap[m] = 0.f;
+            part = fmaf(p[m], Ap[m], part);
+        }
+        const float alpha = rsold / wave_sum(part);
+        part = 0.f;
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            x[m] = fmaf(alpha, p[m], x[m]);
+            r[m] = fmaf(-alpha, Ap[m], r[m]);
+            part = fmaf(r[m], r[m], part);
+        }
+        const float rsnew = wave_sum(part);
+        if (rsnew < 1e-20f) break;
+        const float beta = rsnew / rsold;
+#pragma unroll
+        for (int m = 0; m < NC; ++m) p[m] = fmaf(beta, p[m], r[m]);
+        rsold = rsnew;
+    }
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int col = lane + 64 * m;
+        if (col < F) xg[col] = x[m];
+    }
+}
+
+template <int NT>
+struct SweepLds {
+    static constexpr int F = 32 * NT;
+    static constexpr int BIGN = (F * F > 2 * TR * F) ? F * F : 2 * TR * F;
+    static constexpr int FLOATS = BIGN + 2 * 2 * TR + 2 * F;
+    static constexpr size_t BYTES = (size_t)FLOATS * 4;
+};
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
+    int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G,
+    const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ mslot_ptr,
+    const int32_t* __restrict__ chunk_row, int32_t chunk_nnz, int cg_steps, float* partials) {
+    constexpr int F = 32 * NT;
+    constexpr int NTHR = 64 * NT;
+    using L = SweepLds<NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* big = smem;                                           // A (F x F) / two gather tiles
+    float2* wts = reinterpret_cast<float2*>(smem + L::BIGN);     // [2][TR] (|c|-1, max(c,0))
+    float* bvec = smem + L::BIGN + 2 * 2 * TR;                   // [F]
+    float* vec = bvec + F;                                       // [F] CG broadcast vector
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int h = lane >> 5;
+    const int c = lane & 31;
+
+    const int chunk = blockIdx.x;
+    const int r = chunk_row[chunk];
+    const int cbase = chunk_ptr[r];
+    const int nch = chunk_ptr[r + 1] - cbase;
+    const int lc = chunk - cbase;
+    const int64_t row = row_begin + r;
+    const int64_t rs = indptr[row], re = indptr[row + 1];
+    float* xrow = X + row * F;
+    if (rs == re) {
+        for (int i = tid; i < F; i += NTHR) xrow[i] = 0.f;
+        return;
+    }
+    const int64_t ks = rs + (int64_t)lc * chunk_nnz;
+    const int64_t ke = (ks + chunk_nnz < re) ? ks + chunk_nnz : re;
+    const int ntiles = (int)((ke - ks + TR - 1) / TR);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float bacc = 0.f;
+
+    Staged st;
+    load_tile<NT>(st, indices, data, Y, ks, ke, tid);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        float* tl = big + (tile & 1) * (TR * F);
+        float2* wt = wts + (tile & 1) * TR;
+        store_tile<NT>(st, tl, wt, tid);
+        __syncthreads();
+        if (tile + 1 < ntiles) load_tile<NT>(st, indices, data, Y, ks + (int64_t)(tile + 1) * TR, ke, tid);
+#pragma unroll 4
+        for (int s = 0; s < TR / 2; ++s) {
+            const int k = 2 * s + h;
+            const float2 wc = wt[k];
+            const float a_raw = tl[k * F + w * 32 + c];
+            float b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[t] = tl[k * F + t * 32 + c];
+            const float a = a_raw * wc.x;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+            bacc = fmaf(wc.y, a_raw, bacc);
+        }
+    }
+    const float bsum = bacc + __shfl_xor(bacc, 32, 64);
+    __syncthreads();  // every wave is done with the gather tiles that alias `big`
+
+    if (nch == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = w * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int cc = t * 32 + c;
+                big[rr * F + cc] = acc[t][i] + G[rr * F + cc];
+            }
+        if (h == 0) bvec[w * 32 + c] = bsum;
+        __syncthreads();
+        if (w == 0) cg_solve_wave<F>(big, bvec, vec, xrow, cg_steps, lane);
+    } else {
+        float* P = partials + (size_t)(mslot_ptr[r] + lc) * (F * F + F);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = w * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                P[rr * F + t * 32 + c] = acc[t][i];
+            }
+        if (h == 0) P[F * F + w * 32 + c] = bsum;
+    }
+}
+
+// Split rows: sum the chunk partials in chunk order, add G, solve.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
+    int64_t row_begin, float* X, const float* __restrict__ G, const int32_t* __restrict__ chunk_ptr,
+    const int32_t* __restrict__ mslot_ptr, const int32_t* __restrict__ multi_row, int cg_steps,
+    const float* __restrict__ partials) {
+    constexpr int F = 32 * NT;
+    constexpr int NTHR = 64 * NT;
+    using L = SweepLds<NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* big = smem;
+    float* bvec = smem + L::BIGN + 2 * 2 * TR;
+    float* vec = bvec + F;
+
+    const int tid = threadIdx.x;
+    const int r = multi_row[blockIdx.x];
+    const int nch = chunk_ptr[r + 1] - chunk_ptr[r];
+    const float* P = partials + (size_t)mslot_ptr[r] * (F * F + F);
+    constexpr int STRIDE = F * F + F;
+    for (int e = tid; e < F * F; e += NTHR) {
+        float s = 0.f;
+        for (int ch = 0; ch < nch; ++ch) s += P[(size_t)ch * STRIDE + e];
+        big[e] = s + G[e];
+    }
+    for (int e = tid; e < F; e += NTHR) {
+        float s = 0.f;
+        for (int ch = 0; ch < nch; ++ch) s += P[(size_t)ch * STRIDE + F * F + e];
+        bvec[e] = s;
+    }
+    __syncthreads();
+    if (tid < 64) cg_solve_wave<F>(big, bvec, vec, X + (row_begin + r) * F, cg_steps, tid);
+}
+
+template <int NT>
+static int launch_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
+                        float* X, const float* Y, const float* G, int cg_steps, const char* plan,
+                        const PlanLayout& L, int32_t chunk_nnz, const int64_t counts[3], float* partials,
+                        hipStream_t stream) {
+    using S = SweepLds<NT>;
+    const int32_t* chunk_ptr = (const int32_t*)(plan + L.chunk_ptr);
+    const int32_t* mslot_ptr = (const int32_t*)(plan + L.mslot_ptr);
+    const int32_t* chunk_row = (const int32_t*)(plan + L.chunk_row);
+    const int32_t* multi_row = (const int32_t*)(plan + L.multi_row);
+    static bool attr_done = false;  // idempotent; a race only repeats the call
+    if (!attr_done) {
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_finalize_kernel<NT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
+        attr_done = true;
+    }
+    if (counts[0] > 0) {
+        hipLaunchKernelGGL(als_gram_cg_kernel<NT>, dim3((unsigned)counts[0]), dim3(64 * NT), S::BYTES, stream, indptr,
+                           indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row, chunk_nnz, cg_steps,
+                           partials);
+        MIREC_LAUNCH_CHECK();
+    }
+    if (counts[1] > 0) {
+        hipLaunchKernelGGL(als_finalize_kernel<NT>, dim3((unsigned)counts[1]), dim3(64 * NT), S::BYTES, stream,
+                           row_begin, X, G, chunk_ptr, mslot_ptr, multi_row, cg_steps, partials);
+        MIREC_LAUNCH_CHECK();
+    }
+    return MIREC_OK;
+}
+
+}  // namespace mirec
+
+using namespace mirec;
+
+extern "C" size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk_nnz) {
+    if (nrows < 0 || nnz < 0) return 0;
+    return plan_layout(nrows, nnz, chunk_nnz).total;
+}
+
+extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_end, int64_t nnz, int f,
+                                    void* plan_, size_t plan_bytes, int32_t* chunk_nnz, int64_t host_counts[3],
+                                    mirec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)f;
+    MIREC_REQUIRE(indptr && plan_ && chunk_nnz && host_counts, MIREC_E_INVALID, "mirec_als_plan_build: null argument");
+    MIREC_REQUIRE(row_end >= row_begin && nnz >= 0, MIREC_E_INVALID, "mirec_als_plan_build: bad row range");
+    const int64_t nrows = row_end - row_begin;
+    MIREC_REQUIRE(nrows < (int64_t)1 << 31, MIREC_E_UNSUPPORTED, "mirec_als_plan_build: more than 2^31 rows in one range");
+    int32_t ch = *chunk_nnz;
+    if (ch <= 0) ch = auto_chunk(nnz);
+    MIREC_REQUIRE(ch % TR == 0, MIREC_E_INVALID, "mirec_als_plan_build: chunk_nnz %d is not a multiple of %d", ch, TR);
+    const PlanLayout L = plan_layout(nrows, nnz, ch);
+    MIREC_REQUIRE(plan_bytes >= L.total, MIREC_E_WORKSPACE, "mirec_als_plan_build: plan needs %zu bytes, %zu given",
+                  L.total, plan_bytes);
+    char* plan = (char*)plan_;
+    int32_t* chunk_ptr = (int32_t*)(plan + L.chunk_ptr);
+    int32_t* multi_ptr = (int32_t*)(plan + L.multi_ptr);
+    int32_t* mslot_ptr = (int32_t*)(plan + L.mslot_ptr);
+    int32_t* scratch = (int32_t*)(plan + L.scratch);
+    const int64_t n1 = nrows + 1;
+    hipLaunchKernelGGL(plan_count_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, indptr, row_begin,
+                       nrows, ch, chunk_ptr, multi_ptr, mslot_ptr);
+    MIREC_LAUNCH_CHECK();
+    int rc;
+    if ((rc = exclusive_scan(chunk_ptr, n1, scratch, stream)) != MIREC_OK) return rc;
+    if ((rc = exclusive_scan(multi_ptr, n1, scratch, stream)) != MIREC_OK) return rc;
+    if ((rc = exclusive_scan(mslot_ptr, n1, scratch, stream)) != MIREC_OK) return rc;
+    if (nrows > 0) {
+        hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows,
+                           chunk_ptr, multi_ptr, (int32_t*)(plan + L.chunk_row), (int32_t*)(plan + L.multi_row));
+        MIREC_LAUNCH_CHECK();
+    }
+    int32_t totals[3] = {0, 0, 0};
+    MIREC_HIP(hipMemcpyAsync(&totals[0], chunk_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
+    MIREC_HIP(hipMemcpyAsync(&totals[1], multi_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
+    MIREC_HIP(hipMemcpyAsync(&totals[2], mslot_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
+    MIREC_HIP(hipStreamSynchronize(stream));
+    MIREC_REQUIRE(totals[0] <= L.cap, MIREC_E_INVALID,
+                  "mirec_als_plan_build: %d chunks exceed the plan capacity %lld (nnz argument too small?)", totals[0],
+                  (long long)L.cap);
+    host_counts[0] = totals[0];
+    host_counts[1] = totals[1];
+    host_counts[2] = totals[2];
+    *chunk_nnz = ch;
+    return MIREC_OK;
+}
+
+extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[3], int f) {
+    if (!host_counts || f <= 0) return 0;
+    const size_t slots = host_counts[2] > 0 ? (size_t)host_counts[2] : 1;
+    return slots * ((size_t)f * f + f) * sizeof(float);
+}
+
+extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data,
+                                    int64_t row_begin, int64_t row_end, int64_t nnz, float* X, const float* Y,
+                                    const float* G, int f, int cg_steps, const void* plan, int32_t chunk_nnz,
+                                    const int64_t host_counts[3], void* ws, size_t ws_bytes, mirec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MIREC_REQUIRE(indptr && X && Y && G && plan && host_counts, MIREC_E_INVALID, "mirec_als_half_sweep: null argument");
+    MIREC_REQUIRE(nnz == 0 || (indices && data), MIREC_E_INVALID, "mirec_als_half_sweep: null indices/data");
+    MIREC_REQUIRE(row_end >= row_begin && cg_steps >= 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad range or cg_steps");
+    MIREC_REQUIRE(f % 32 == 0 && f >= 32 && f <= 192, MIREC_E_UNSUPPORTED,
+                  "mirec_als_half_sweep: factor width %d is not a multiple of 32 in [32,192]; zero-pad the columns", f);
+    MIREC_REQUIRE(chunk_nnz > 0 && chunk_nnz % TR == 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad chunk_nnz %d",
+                  chunk_nnz);
+    MIREC_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, MIREC_E_INVALID,
+                  "mirec_als_half_sweep: factor matrices must be 16-byte aligned");
+    MIREC_REQUIRE(host_counts[2] == 0 || (ws && ws_bytes >= mirec_als_sweep_workspace_bytes(host_counts, f)),
+                  MIREC_E_WORKSPACE, "mirec_als_half_sweep: workspace of %zu bytes needed, %zu given",
+                  mirec_als_sweep_workspace_bytes(host_counts, f), ws_bytes);
+    const int64_t nrows = row_end - row_begin;
+    if (nrows == 0) return MIREC_OK;
+    const PlanLayout L = plan_layout(nrows, nnz, chunk_nnz);
+    const char* p = (const char*)plan;
+    float* partials = (float*)ws;
+    switch (f / 32) {
+        case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
+        case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
+        case 3: return launch_sweep<3>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
+        case 4: return launch_sweep<4>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
+        case 5: return launch_sweep<5>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
+        case 6: return launch_sweep<6>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
+    }
+    return MIREC_E_UNSUPPORTED;
+}

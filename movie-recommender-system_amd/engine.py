@@ -1,0 +1,222 @@
+"""Device-side plumbing between PyTorch-ROCm tensors and the C ABI.
+
+PyTorch is used for what it is good at here -- device memory, streams and (in
+``dist.py``) RCCL -- while every arithmetic step of the hot path is a libmirec
+call.  Classes:
+
+``DeviceCSR``   a CSR matrix resident in HBM (int64 indptr, int32 indices, fp32 data)
+``SweepPlan``   the chunk plan + partial-Gram workspace of one half-sweep
+``AlsEngine``   factor matrices, plans and workspaces of one fit; one
+                ``iteration()`` = user half-sweep + item half-sweep, as in
+                implicit's ``fit`` loop (reference call sites ``als/als.py:174``,
+                ``recommenders/als_recommender.py:136``)
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+
+
+def _stream_ptr() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def require_cuda(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.MirecError("no HIP device is visible: the recommender core runs on MI355X only (no CPU fallback)")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.MirecError(f"device {dev} is not a HIP device")
+    return dev
+
+
+def factor_width(f: int, for_scoring: bool = False) -> int:
+    w = _lib.require().mirec_factor_width(int(f), 1 if for_scoring else 0)
+    if w < 0:
+        raise _lib.MirecError(f"factor width {f} exceeds what the kernels are built for (192)")
+    return int(w)
+
+
+def pad_factors(a: np.ndarray, width: int, device: torch.device) -> torch.Tensor:
+    """Upload [n, f] fp32 as a zero-padded [n, width] device matrix."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    n, f = a.shape
+    out = torch.zeros((n, width), dtype=torch.float32, device=device)
+    if n:
+        out[:, :f] = torch.from_numpy(a).to(device)
+    return out
+
+
+class DeviceCSR:
+    """CSR matrix in HBM.  ``indptr`` holds offsets into this object's own
+    ``indices``/``data`` (it starts at 0)."""
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor, shape: Tuple[int, int]):
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32 and data.dtype == torch.float32
+        self.indptr, self.indices, self.data = indptr, indices, data
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.nnz = int(indices.numel())
+
+    @classmethod
+    def from_scipy(cls, m: sp.csr_matrix, device: torch.device, scale: float = 1.0) -> "DeviceCSR":
+        m = sp.csr_matrix(m)
+        indptr = torch.from_numpy(np.ascontiguousarray(m.indptr, dtype=np.int64)).to(device)
+        indices = torch.from_numpy(np.ascontiguousarray(m.indices, dtype=np.int32)).to(device)
+        data = np.ascontiguousarray(m.data, dtype=np.float32)
+        if scale != 1.0:
+            data = data * np.float32(scale)
+        return cls(indptr, indices, torch.from_numpy(data).to(device), m.shape)
+
+    def transpose(self) -> "DeviceCSR":
+        """``.T.tocsr()`` on the device (stable sort by column)."""
+        lib = _lib.require()
+        rows, cols = self.shape
+        dev = self.indptr.device
+        ws_bytes = lib.mirec_csr_transpose_workspace_bytes(rows, cols, self.nnz)
+        ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)
+        t_indptr = torch.empty(cols + 1, dtype=torch.int64, device=dev)
+        t_indices = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+        t_data = torch.empty(self.nnz, dtype=torch.float32, device=dev)
+        _lib.check(lib.mirec_csr_transpose(_ptr(self.indptr), _ptr(self.indices), _ptr(self.data), rows, cols, self.nnz,
+                                           _ptr(t_indptr), _ptr(t_indices), _ptr(t_data), _ptr(ws), ws_bytes,
+                                           _stream_ptr()), "mirec_csr_transpose")
+        # `ws` may be freed by the caching allocator only after the kernels that use it: same stream, so safe.
+        return DeviceCSR(t_indptr, t_indices, t_data, (cols, rows))
+
+    def row_slice(self, r0: int, r1: int) -> "DeviceCSR":
+        """Rows [r0, r1) as a CSR of their own (copies the pointer array only)."""
+        s = int(self.indptr[r0].item())
+        e = int(self.indptr[r1].item())
+        return DeviceCSR((self.indptr[r0:r1 + 1] - s).contiguous(), self.indices[s:e], self.data[s:e],
+                         (r1 - r0, self.shape[1]))
+
+    def to_scipy(self) -> sp.csr_matrix:
+        return sp.csr_matrix((self.data.cpu().numpy(), self.indices.cpu().numpy(), self.indptr.cpu().numpy()),
+                             shape=self.shape)
+
+
+def gram(Y: torch.Tensor, reg: float, out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+    """G = Y^T Y + reg I for a padded device factor matrix."""
+    lib = _lib.require()
+    n, f = Y.shape
+    need = lib.mirec_gram_workspace_bytes(n, f)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=Y.device)
+    if out is None:
+        out = torch.empty((f, f), dtype=torch.float32, device=Y.device)
+    _lib.check(lib.mirec_gram(_ptr(Y), n, f, float(reg), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), "mirec_gram")
+    return out
+
+
+class SweepPlan:
+    """Chunk plan of one CSR row range for a given factor width."""
+
+    def __init__(self, csr: DeviceCSR, f: int, chunk_nnz: int = 0):
+        lib = _lib.require()
+        self.csr, self.f = csr, int(f)
+        nrows = csr.shape[0]
+        dev = csr.indptr.device
+        nbytes = lib.mirec_als_plan_bytes(nrows, csr.nnz, int(chunk_nnz))
+        self.plan = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+        chunk = ctypes.c_int32(int(chunk_nnz))
+        self.counts = (ctypes.c_int64 * 3)()
+        _lib.check(lib.mirec_als_plan_build(_ptr(csr.indptr), 0, nrows, csr.nnz, self.f, _ptr(self.plan),
+                                            self.plan.numel(), ctypes.byref(chunk), self.counts, _stream_ptr()),
+                   "mirec_als_plan_build")
+        self.chunk_nnz = int(chunk.value)
+        ws_bytes = lib.mirec_als_sweep_workspace_bytes(self.counts, self.f)
+        self.ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)
+
+    @property
+    def n_chunks(self) -> int:
+        return int(self.counts[0])
+
+    @property
+    def n_split_rows(self) -> int:
+        return int(self.counts[1])
+
+    def sweep(self, X_rows: torch.Tensor, Y: torch.Tensor, G: torch.Tensor, cg_steps: int = 3) -> None:
+        """Solve the plan's rows in place: ``X_rows`` is the [nrows, f] block of
+        the factor matrix that belongs to these CSR rows."""
+        lib = _lib.require()
+        csr = self.csr
+        assert X_rows.shape == (csr.shape[0], self.f) and X_rows.is_contiguous()
+        assert Y.shape[1] == self.f and Y.is_contiguous() and Y.shape[0] >= csr.shape[1]
+        _lib.check(lib.mirec_als_half_sweep(_ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.data), 0, csr.shape[0],
+                                            csr.nnz, _ptr(X_rows), _ptr(Y), _ptr(G), self.f, int(cg_steps),
+                                            _ptr(self.plan), self.chunk_nnz, self.counts, _ptr(self.ws),
+                                            self.ws.numel(), _stream_ptr()), "mirec_als_half_sweep")
+
+
+class AlsEngine:
+    """All device state of one ALS fit on one GPU.
+
+    ``user_rows`` / ``item_rows`` restrict the rows this engine solves (the
+    shard of one rank); the factor matrices are always held whole.
+    """
+
+    def __init__(self, Cui: DeviceCSR, Ciu: Optional[DeviceCSR], X: torch.Tensor, Y: torch.Tensor,
+                 regularization: float, cg_steps: int = 3, user_rows: Optional[Tuple[int, int]] = None,
+                 item_rows: Optional[Tuple[int, int]] = None, chunk_nnz: int = 0):
+        self.f = int(X.shape[1])
+        assert Y.shape[1] == self.f
+        self.X, self.Y = X, Y
+        self.reg, self.cg_steps = float(regularization), int(cg_steps)
+        users, items = Cui.shape
+        if Ciu is None:
+            Ciu = Cui.transpose()
+        self.user_rows = user_rows or (0, users)
+        self.item_rows = item_rows or (0, items)
+        cu = Cui if self.user_rows == (0, users) else Cui.row_slice(*self.user_rows)
+        ci = Ciu if self.item_rows == (0, items) else Ciu.row_slice(*self.item_rows)
+        self.Cui_local, self.Ciu_local = cu, ci
+        self.plan_u = SweepPlan(cu, self.f, chunk_nnz)
+        self.plan_i = SweepPlan(ci, self.f, chunk_nnz)
+        lib = _lib.require()
+        need = max(lib.mirec_gram_workspace_bytes(users, self.f), lib.mirec_gram_workspace_bytes(items, self.f))
+        self.gram_ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=X.device)
+        self.G = torch.empty((self.f, self.f), dtype=torch.float32, device=X.device)
+
+    def user_sweep(self) -> None:
+        gram(self.Y, self.reg, self.G, self.gram_ws)
+        u0, u1 = self.user_rows
+        self.plan_u.sweep(self.X[u0:u1], self.Y, self.G, self.cg_steps)
+
+    def item_sweep(self) -> None:
+        gram(self.X, self.reg, self.G, self.gram_ws)
+        i0, i1 = self.item_rows
+        self.plan_i.sweep(self.Y[i0:i1], self.X, self.G, self.cg_steps)
+
+    def iteration(self) -> None:
+        self.user_sweep()
+        self.item_sweep()
+
+
+def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = None,
+         y_norm: Optional[torch.Tensor] = None, q_norm: Optional[torch.Tensor] = None,
+         n_items: Optional[int] = None):
+    """Fused score + top-k of every row of Q against the first n_items rows of Y.
+    Returns device tensors (ids int32 [nq, k], scores fp32 [nq, k])."""
+    lib = _lib.require()
+    nq, f = Q.shape
+    ni = int(Y.shape[0] if n_items is None else n_items)
+    assert Y.shape[1] == f and Q.is_contiguous() and Y.is_contiguous()
+    if mask is not None:
+        assert mask.shape[0] == nq, "one mask row per query"
+    ids = torch.empty((nq, k), dtype=torch.int32, device=Q.device)
+    scores = torch.empty((nq, k), dtype=torch.float32, device=Q.device)
+    _lib.check(lib.mirec_topk(_ptr(Q), nq, _ptr(Y), ni, f, _ptr(None if mask is None else mask.indptr),
+                              _ptr(None if mask is None else mask.indices), _ptr(y_norm), _ptr(q_norm), int(k),
+                              _ptr(ids), _ptr(scores), _stream_ptr()), "mirec_topk")
+    return ids, scores

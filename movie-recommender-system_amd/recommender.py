@@ -1,0 +1,207 @@
+"""``ALSRecommender``: the serving plugin, loadable through a manifest line
+``class_path: "movie_recommender_system_amd.recommender:ALSRecommender"``.
+
+Mirrors the reference plugin (``recommenders/als_recommender.py:26-337``)
+method for method -- constructor config (manifest ``runtime`` + ``artefacts`` +
+``metadata``), ``load_model`` / ``teardown`` / ``train`` / ``save_model``,
+``recommend_for_user`` with the popular-items fallback for unknown users and
+for any scoring exception, ``get_similar_items`` (asks for N+1 and drops the
+item itself), ``get_user_profile``, ``get_model_stats`` -- with the numeric
+calls going to this package's GPU model instead of ``implicit``.
+"""
+
+from __future__ import annotations
+
+import gc
+import pickle
+from pathlib import Path
+from typing import Any, Dict
+
+import numpy as np
+from scipy.sparse import load_npz
+
+from .als import AlternatingLeastSquares
+from .artifacts import popularity_order
+from .base import BaseRecommender, ModelNotLoadedException, RecommendationResult, SimilarItemsResult
+
+
+class ALSRecommender(BaseRecommender):
+    """ALS recommender with cold-start fallback, GPU-backed."""
+
+    DEFAULT_HYPERPARAMETERS = {"factors": 64, "iterations": 20, "regularization": 0.01, "alpha": 40,
+                               "random_state": 42}
+
+    def __init__(self, config: Dict[str, Any], model_name: str = "als"):
+        super().__init__(config, model_name)
+        self.model = None
+        self.train_matrix = None
+        self.user_mappings = None
+        self.movie_mappings = None
+        self.most_popular_movies = None
+        runtime = dict(config)
+        self.artefacts = runtime.pop("artefacts", {})
+        self.metadata = runtime.pop("metadata", {})
+        self.use_gpu = runtime.get("use_gpu", True)
+        self.device = runtime.get("device")
+        self.runtime_overrides = runtime
+        self.hyperparameters = dict(self.metadata.get("hyperparameters", {}))
+
+    # ---------------------------------------------------------------- lifecycle
+    def load_model(self, model_dir: str) -> None:
+        root = Path(model_dir)
+        try:
+            matrix_path = root / self.artefacts.get("train_matrix", "train_matrix.npz")
+            users_path = root / self.artefacts.get("user_mappings", "user_mappings.pkl")
+            movies_path = root / self.artefacts.get("movie_mappings", "movie_mappings.pkl")
+            model_path = root / self.artefacts.get("model", "als_model.pkl")
+            for label, path in (("Training matrix", matrix_path), ("User mappings", users_path),
+                                ("Movie mappings", movies_path), ("Serialized ALS model", model_path)):
+                if not path.exists():
+                    raise FileNotFoundError(f"{label} not found: {path}")
+            self.train_matrix = load_npz(str(matrix_path)).tocsr()
+            with open(users_path, "rb") as fh:
+                self.user_mappings = pickle.load(fh)
+            with open(movies_path, "rb") as fh:
+                self.movie_mappings = pickle.load(fh)
+            self.user_mappings.setdefault("n_users", len(self.user_mappings["user_to_idx"]))
+            self.movie_mappings.setdefault("n_movies", len(self.movie_mappings["movie_to_idx"]))
+            with open(model_path, "rb") as fh:
+                blob = pickle.load(fh)
+            self.model = blob["model"]
+            self.most_popular_movies = blob["most_popular_movies"]
+            self.hyperparameters = blob.get("model_params", self.hyperparameters)
+            self.is_loaded = True
+        except Exception:
+            self.is_loaded = False
+            raise
+
+    def warmup(self) -> None:
+        """Upload the item factors and run one scoring pass so the first request
+        does not pay for it."""
+        if self.is_loaded and self.model is not None and self.train_matrix.shape[0] > 0:
+            self.model.recommend(0, self.train_matrix[0], N=1, filter_already_liked_items=True)
+
+    def teardown(self) -> None:
+        self.model = None
+        self.train_matrix = None
+        self.user_mappings = None
+        self.movie_mappings = None
+        self.most_popular_movies = None
+        self.is_loaded = False
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ----------------------------------------------------------------- training
+    def _train_model(self, hyperparameters: Dict[str, Any]) -> None:
+        if self.train_matrix is None:
+            raise ValueError("Training matrix not loaded")
+        hp = {**self.DEFAULT_HYPERPARAMETERS, **hyperparameters}
+        self.model = AlternatingLeastSquares(
+            factors=hp["factors"], iterations=hp["iterations"], regularization=hp["regularization"],
+            alpha=hp["alpha"], random_state=hp["random_state"], use_gpu=True, device=self.device)
+        self.model.fit(self.train_matrix)
+        self.most_popular_movies = popularity_order(self.train_matrix, "sort_then_reverse")
+
+    def train(self, training_config: Dict[str, Any]) -> None:
+        artefacts = training_config.get("artefacts") or {}
+        try:
+            self.train_matrix = artefacts["train_matrix"]
+            self.user_mappings = artefacts["user_mappings"]
+            self.movie_mappings = artefacts["movie_mappings"]
+        except KeyError as missing:
+            raise ValueError(f"Missing required artefact for ALS training: {missing}") from missing
+        params = training_config.get("hyperparameters", {})
+        self.hyperparameters = params
+        self._train_model(params)
+        self.is_loaded = True
+
+    def save_model(self, model_dir: str) -> None:
+        if not self.is_loaded or self.model is None:
+            raise ModelNotLoadedException("No model loaded to save")
+        root = Path(model_dir)
+        root.mkdir(parents=True, exist_ok=True)
+        params = dict(self.hyperparameters) or {k: getattr(self.model, k, None)
+                                               for k in ("factors", "iterations", "regularization", "alpha")}
+        with open(root / "als_model.pkl", "wb") as fh:
+            pickle.dump({"model": self.model, "most_popular_movies": self.most_popular_movies,
+                         "model_params": params}, fh)
+
+    # ------------------------------------------------------------------ serving
+    def recommend_for_user(self, user_id: str, N: int = 10) -> RecommendationResult:
+        if not self.is_loaded:
+            raise ModelNotLoadedException("ALS model not loaded")
+        if user_id in self.user_mappings["user_to_idx"]:
+            return self._recommend_for_known_user(user_id, N)
+        return self._recommend_for_new_user(user_id, N)
+
+    def _recommend_for_known_user(self, user_id: str, N: int) -> RecommendationResult:
+        user_idx = self.user_mappings["user_to_idx"][user_id]
+        try:
+            ids, scores = self.model.recommend(user_idx, self.train_matrix[user_idx], N=N,
+                                               filter_already_liked_items=True)
+            idx_to_movie = self.movie_mappings["idx_to_movie"]
+            recs = [{"movie_id": idx_to_movie[int(i)], "score": float(s), "rank": rank}
+                    for rank, (i, s) in enumerate(zip(ids, scores), start=1) if i >= 0]
+            return RecommendationResult(user_id=user_id, user_type="known", method="ALS", recommendations=recs,
+                                        total_count=len(recs), model_name=self.model_name)
+        except Exception as exc:  # noqa: BLE001 - same contract as the reference: never fail a request
+            self.logger.error("Error generating ALS recommendations for %s: %s", user_id, exc)
+            return self._recommend_for_new_user(user_id, N)
+
+    def _recommend_for_new_user(self, user_id: str, N: int) -> RecommendationResult:
+        idx_to_movie = self.movie_mappings["idx_to_movie"]
+        recs = [{"movie_id": idx_to_movie[int(i)], "score": None, "rank": rank}
+                for rank, i in enumerate(self.most_popular_movies[:N], start=1)]
+        return RecommendationResult(user_id=user_id, user_type="new", method="most_popular", recommendations=recs,
+                                    total_count=len(recs), model_name=self.model_name)
+
+    def get_similar_items(self, item_id: str, N: int = 10) -> SimilarItemsResult:
+        if not self.is_loaded:
+            raise ModelNotLoadedException("ALS model not loaded")
+        if item_id not in self.movie_mappings["movie_to_idx"]:
+            return SimilarItemsResult(item_id=item_id, item_type="movie", similar_items=[], total_count=0,
+                                      model_name=self.model_name, error="Movie not found in training data")
+        movie_idx = self.movie_mappings["movie_to_idx"][item_id]
+        try:
+            ids, scores = self.model.similar_items(movie_idx, N=N + 1)
+            idx_to_movie = self.movie_mappings["idx_to_movie"]
+            sims = [{"movie_id": idx_to_movie[int(i)], "similarity_score": float(s), "rank": rank}
+                    for rank, (i, s) in enumerate(zip(ids[1:], scores[1:]), start=1) if i >= 0][:N]
+            return SimilarItemsResult(item_id=item_id, item_type="movie", similar_items=sims, total_count=len(sims),
+                                      model_name=self.model_name)
+        except Exception as exc:  # noqa: BLE001
+            self.logger.error("Error finding similar movies for %s: %s", item_id, exc)
+            return SimilarItemsResult(item_id=item_id, item_type="movie", similar_items=[], total_count=0,
+                                      model_name=self.model_name, error=str(exc))
+
+    def get_user_profile(self, user_id: str) -> Dict[str, Any]:
+        if not self.is_loaded:
+            raise ModelNotLoadedException("ALS model not loaded")
+        if user_id not in self.user_mappings["user_to_idx"]:
+            return {"user_id": user_id, "user_type": "new", "interactions_count": 0, "liked_movies": [],
+                    "model_name": self.model_name}
+        row = self.train_matrix[self.user_mappings["user_to_idx"][user_id]]
+        liked = [self.movie_mappings["idx_to_movie"][int(i)] for i in row.nonzero()[1]]
+        return {"user_id": user_id, "user_type": "known", "interactions_count": len(liked), "liked_movies": liked,
+                "model_name": self.model_name}
+
+    def get_model_stats(self) -> Dict[str, Any]:
+        if not self.is_loaded:
+            raise ModelNotLoadedException("ALS model not loaded")
+        rows, cols = self.train_matrix.shape
+        cells = rows * cols
+        return {
+            "model_name": self.model_name,
+            "model_type": "ALS",
+            "n_users": self.user_mappings["n_users"],
+            "n_movies": self.movie_mappings["n_movies"],
+            "matrix_shape": self.train_matrix.shape,
+            "n_interactions": self.train_matrix.nnz,
+            "sparsity": (cells - self.train_matrix.nnz) / cells * 100,
+            "hyperparameters": {**self.hyperparameters, "use_gpu": self.use_gpu},
+        }

@@ -1,0 +1,166 @@
+"""GPU parity of fused score + top-K, similar-items and LightFM scoring against
+the oracle: ids AND scores must be bit-identical (the device evaluates the same
+ascending-k fma chain; ties break by ascending item index)."""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def run_topk(dev, Q, Y, k, liked=None, y_norm=None, q_norm=None):
+    import torch
+    from movie_recommender_system_amd import engine as E
+    W = E.factor_width(Q.shape[1], for_scoring=True)
+    dQ, dY = E.pad_factors(Q, W, dev), E.pad_factors(Y, W, dev)
+    mask = None if liked is None else E.DeviceCSR.from_scipy(liked, dev)
+    yn = None if y_norm is None else torch.from_numpy(y_norm).to(dev)
+    qn = None if q_norm is None else torch.from_numpy(q_norm).to(dev)
+    ids, sc = E.topk(dQ, dY, k, mask, yn, qn)
+    return ids.cpu().numpy(), sc.cpu().numpy()
+
+
+@pytest.mark.parametrize("nq,ni,f,k", [
+    (1, 1, 8, 1), (3, 50, 2, 20), (129, 1000, 64, 20), (500, 2777, 128, 20), (200, 300, 100, 32),
+    (77, 640, 48, 33), (64, 900, 16, 100), (130, 129, 192, 10), (40, 4097, 24, 224),
+])
+def test_topk_bit_exact(dev, nq, ni, f, k):
+    rng = np.random.default_rng(nq + ni + f + k)
+    Q = rng.standard_normal((nq, f)).astype(np.float32)
+    Y = rng.standard_normal((ni, f)).astype(np.float32)
+    liked = sp.random(nq, ni, density=min(0.05, 20.0 / ni), random_state=np.random.RandomState(k), format="csr",
+                      dtype=np.float32)
+    liked.sort_indices()
+    ids, sc = run_topk(dev, Q, Y, k, liked)
+    oid, osc = oracle.topk(Q, Y, k, liked=liked)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(sc, osc)
+    ids2, sc2 = run_topk(dev, Q, Y, k, None)
+    oid2, osc2 = oracle.topk(Q, Y, k)
+    assert np.array_equal(ids2, oid2) and np.array_equal(sc2, osc2)
+
+
+def test_topk_ties_and_degenerate_rows(dev):
+    """Zero query rows score every item exactly 0.0 (implicit zeroes users
+    without interactions): ties resolve by ascending item index; duplicated
+    items tie pairwise."""
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((300, 32)).astype(np.float32)
+    Y[100:200] = Y[0:100]
+    Q = rng.standard_normal((70, 32)).astype(np.float32)
+    Q[::3] = 0.0
+    liked = sp.csr_matrix((np.ones(70, dtype=np.float32), (np.arange(70), np.arange(70) % 5)), shape=(70, 300))
+    ids, sc = run_topk(dev, Q, Y, 20, liked)
+    oid, osc = oracle.topk(Q, Y, 20, liked=liked)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    zero_rows = ids[::3]
+    for u, row in zip(range(0, 70, 3), zero_rows):
+        expect = [i for i in range(25) if i != u % 5][:20]
+        assert row.tolist() == expect
+
+
+def test_topk_fewer_items_than_k_and_all_liked(dev):
+    rng = np.random.default_rng(1)
+    Q = rng.standard_normal((5, 16)).astype(np.float32)
+    Y = rng.standard_normal((7, 16)).astype(np.float32)
+    liked = sp.csr_matrix(np.ones((5, 7), dtype=np.float32))
+    liked[0, :] = 0
+    liked = sp.csr_matrix(liked)
+    liked.eliminate_zeros()
+    ids, sc = run_topk(dev, Q, Y, 20, liked)
+    oid, osc = oracle.topk(Q, Y, 20, liked=liked)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    assert (ids[:, 7:] == -1).all()
+    assert (sc[1:, :7] == -np.finfo(np.float32).max).all()
+
+
+def test_topk_ascending_scores_worst_case(dev):
+    """Scores that grow with the item index defeat the threshold filter: every
+    item is a candidate and the buffers compact constantly."""
+    ni, f = 3000, 8
+    Y = np.zeros((ni, f), dtype=np.float32)
+    Y[:, 0] = np.arange(ni, dtype=np.float32)
+    Q = np.zeros((40, f), dtype=np.float32)
+    Q[:, 0] = 1.0
+    Q[20:, 0] = -1.0
+    for k in (20, 100):
+        ids, sc = run_topk(dev, Q, Y, k)
+        oid, osc = oracle.topk(Q, Y, k)
+        assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+
+
+def test_model_recommend_and_similar_items(dev):
+    from movie_recommender_system_amd import AlternatingLeastSquares
+    rng = np.random.default_rng(2)
+    model = AlternatingLeastSquares(factors=20)
+    model.user_factors = rng.standard_normal((50, 20)).astype(np.float32)
+    model.item_factors = rng.standard_normal((400, 20)).astype(np.float32)
+    model.item_factors[7] = 0.0
+    M = sp.random(50, 400, density=0.03, random_state=np.random.RandomState(4), format="csr", dtype=np.float32)
+    M.sort_indices()
+    ids, sc = model.recommend(3, M[3], N=10, filter_already_liked_items=True)
+    oid, osc = oracle.topk(model.user_factors[3:4], model.item_factors, 10, liked=M[3])
+    assert ids.shape == (10,) and ids.dtype == np.int32 and sc.dtype == np.float32
+    assert np.array_equal(ids, oid[0]) and np.array_equal(sc, osc[0])
+    users = np.array([4, 9, 0])
+    ids, sc = model.recommend(users, M[users], N=7)
+    oid, osc = oracle.topk(model.user_factors[users], model.item_factors, 7, liked=M[users])
+    assert ids.shape == (3, 7) and np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    with pytest.raises(ValueError):
+        model.recommend(3, M, N=10)  # the pre-0.5 call shape of als/als.py:206-211
+    # similar_items: cosine, self first
+    norms = np.linalg.norm(model.item_factors, axis=-1).astype(np.float32)
+    norms[norms == 0] = 1e-10
+    sid, ssc = model.similar_items(11, N=6)
+    oid, osc = oracle.topk(model.item_factors[11:12], model.item_factors, 6, y_norm=norms, q_norm=norms[11:12])
+    assert sid[0] == 11 and np.array_equal(sid, oid[0]) and np.array_equal(ssc, osc[0])
+    assert abs(ssc[0] - 1.0) < 1e-5
+
+
+def test_lightfm_scoring_bit_exact(dev):
+    from movie_recommender_system_amd import LightFMScorer, synth
+    from movie_recommender_system_amd.lightfm import compute_recommendations
+    p = synth.lightfm_problem(5, 700, 333)
+    sc = LightFMScorer(p["user_embeddings"], p["user_biases"], p["item_embeddings"], p["item_biases"])
+    ur = oracle.lightfm_repr(p["user_features"], p["user_embeddings"], p["user_biases"])
+    ir = oracle.lightfm_repr(p["item_features"], p["item_embeddings"], p["item_biases"])
+    gu, gi = sc.representations(p["user_features"], p["item_features"])
+    assert np.array_equal(gu, ur) and np.array_equal(gi, ir)
+    # predict exactly as hybrid_docker/inference.py:156-165 calls it
+    n_items = p["item_features"].shape[0]
+    item_ids = np.arange(n_items, dtype=np.int32)
+    user_ids = np.full(n_items, 42, dtype=np.int32)
+    got = sc.predict(user_ids, item_ids, user_features=p["user_features"], item_features=p["item_features"],
+                     num_threads=4)
+    want = oracle.lightfm_predict(ur, ir, user_ids, item_ids)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    top = got.argsort()[::-1][:20]
+    for k in (20, 1, 100):
+        ids, scores = sc.recommend(None, p["user_features"], p["item_features"], k=k)
+        oid, osc = oracle.lightfm_topk(ur, ir, k)
+        assert np.array_equal(ids, oid) and np.array_equal(scores, osc)
+    ids, _ = sc.recommend([42], p["user_features"], p["item_features"], k=20)
+    assert set(ids[0].tolist()) == set(top.tolist()) or np.unique(got[top]).size < 20
+    # cold start: three feature tokens, no identity feature (inference.py:168-194)
+    n_users = 700
+    fmap = {f"tok{j}": n_users + j for j in range(30)}
+    state = {"model": sc, "user_features": p["user_features"], "item_features": p["item_features"],
+             "inv_item_map": {i: f"movie{i}" for i in range(n_items)}, "user_to_idx": {"u42": 42},
+             "user_feature_mapping": fmap}
+    recs = compute_recommendations("someone-new", state, 20, ["tok1", "tok9", "tok29", "unknown-token"])
+    row = sp.csr_matrix((np.ones(3, dtype=np.float32), ([0, 0, 0], [n_users + 1, n_users + 9, n_users + 29])),
+                        shape=(1, p["user_features"].shape[1]))
+    cold = oracle.lightfm_repr(row, p["user_embeddings"], p["user_biases"])
+    oid, _ = oracle.lightfm_topk(cold, ir, 20)
+    assert recs == [f"movie{i}" for i in oid[0]]
+    assert compute_recommendations("u42", state, 20) == [f"movie{i}" for i in ids[0]]
