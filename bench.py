@@ -1,0 +1,267 @@
+"""Benchmark of the recommender hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): implicit-feedback ALS with factors=128,
+fp32, on synthetic 1 M users x 27 k movies (~5e7 interactions, seed 42), then
+the top-20 recommend pass for all users from the trained factors.  One "step" is
+one ALS iteration = user half-sweep + item half-sweep (both Grams and, with
+N > 1, both all-gathers).  The problem size is fixed as N grows (strong
+scaling): users and items are sharded across the ranks by stored entries.
+
+Rank 0 prints ONE JSON line.  `value` is seconds per ALS iteration (max over
+ranks, inputs resident in HBM).  `roofline` describes the dominant kernel
+(als_gram_cg_kernel): algorithmic bytes per launch / live HIP-event time per
+launch against the 8 TB/s HBM peak.  `cpu_baseline` times the CPU oracle (a
+restatement of implicit 0.7.2's CG solver) on a bounded sample of the same
+matrix on the host cores.  `extra` carries the top-20 pass (users/s, fp32 MFMA
+roofline) and the per-kernel times.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=27_000)
+    ap.add_argument("--mean-degree", type=float, default=50.0)
+    ap.add_argument("--factors", type=int, default=128)
+    ap.add_argument("--alpha", type=float, default=40.0)
+    ap.add_argument("--regularization", type=float, default=0.01)
+    ap.add_argument("--topk", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (0 = skip)")
+    ap.add_argument("--no-topk", action="store_true")
+    ap.add_argument("--no-lightfm", action="store_true")
+    return ap.parse_args()
+
+
+def sweep_bytes(nnz: int, rows: int, f: int) -> float:
+    """Algorithmic bytes of one half-sweep: every stored entry gathers one factor
+    row (4f) plus its index and value (8); every solved row is read and written
+    once (2*4f); the row pointers once."""
+    return nnz * (4.0 * f + 8.0) + rows * 8.0 * f + (rows + 1) * 8.0
+
+
+def cpu_baseline(indptr, indices, data, t_indptr, t_indices, t_data, users, items, f, reg, budget_s, seed):
+    """Time the oracle's half-sweeps on leading row blocks sized to the budget
+    and extrapolate by stored entries to one full iteration."""
+    import scipy.sparse as sp
+    import oracle
+
+    threads = oracle.num_threads()
+    rs = np.random.RandomState(seed)
+    X = rs.rand(users, f).astype(np.float32) * 0.01
+    Y = rs.rand(items, f).astype(np.float32) * 0.01
+    Cui = sp.csr_matrix((data, indices, indptr), shape=(users, items))
+    Ciu = sp.csr_matrix((t_data, t_indices, t_indptr), shape=(items, users))
+
+    def timed(C, A, B, n_rows_total, budget):
+        G = (B.T @ B + reg * np.eye(f, dtype=np.float32)).astype(np.float32)
+        probe = max(1, n_rows_total // 200)
+        t0 = time.perf_counter()
+        oracle.als_half_sweep(C, A, B, reg, 3, rows=(0, probe), YtY=G)
+        tp = time.perf_counter() - t0
+        nnz_probe = int(C.indptr[probe] - C.indptr[0])
+        rate = max(nnz_probe, 1) / max(tp, 1e-6)           # entries / s
+        target_nnz = rate * budget
+        rows = int(np.searchsorted(C.indptr, C.indptr[probe] + target_nnz))
+        rows = max(min(rows, n_rows_total), probe + 1)
+        t0 = time.perf_counter()
+        oracle.als_half_sweep(C, A, B, reg, 3, rows=(probe, rows), YtY=G)
+        t = time.perf_counter() - t0
+        nnz_s = int(C.indptr[rows] - C.indptr[probe])
+        return t, nnz_s, rows - probe
+
+    tu, nnz_u, rows_u = timed(Cui, X, Y, users, budget_s / 2)
+    ti, nnz_i, rows_i = timed(Ciu, Y, X, items, budget_s / 2)
+    nnz = int(indptr[-1])
+    est = tu * nnz / max(nnz_u, 1) + ti * nnz / max(nnz_i, 1)
+    return {
+        "value": est, "unit": "s/iteration", "cores": threads, "kind": "port",
+        "sample": (f"oracle half-sweeps (restatement of implicit 0.7.2 CG, OpenMP {threads} threads) on "
+                   f"{rows_u} user rows ({nnz_u} entries, {tu:.2f} s) and {rows_i} item rows ({nnz_i} entries, "
+                   f"{ti:.2f} s) of the same matrix, f={f}; scaled by stored entries to one iteration"),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from movie_recommender_system_amd import engine as E
+    from movie_recommender_system_amd import dist as D
+    from movie_recommender_system_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    U, I, f = args.users, args.items, args.factors
+    F = E.factor_width(f)
+    t_setup = time.perf_counter()
+    indptr, indices, data = synth.interactions_torch(args.seed, U, I, args.mean_degree, dev)
+    nnz = int(indices.numel())
+    Cui = E.DeviceCSR(indptr, indices, data * args.alpha, (U, I))   # fit() multiplies the stored values by alpha
+    Ciu = Cui.transpose()
+    rs = np.random.RandomState(args.seed)
+    X = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, F, dev)
+    Y = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, F, dev)
+    drv, eng = D.gpu_driver(Cui, Ciu, X, Y, args.regularization, 3, rank, world)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    for _ in range(args.warmup):
+        drv.iteration()
+    eng.events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.iteration()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    times = eng.event_times_ms()
+    eng.events = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    s_per_iter = elapsed / args.steps
+
+    # ---- roofline: one entry per half-sweep kernel (live HIP-event time per launch, algorithmic bytes of
+    # the rows that kernel solved); the dominant one (more time per iteration) is reported as `roofline`.
+    def side(tag, csr, plan):
+        rows, nz = csr.shape[0], csr.nnz
+        n_short = plan.n_short_rows
+        out = []
+        t_s, c_s = times.get(tag + "_short", (0.0, 0))
+        t_m, c_m = times.get(tag + "_main", (0.0, 0))
+        # stored entries are attributed to the two kernels by their share of the rows' entries; at the
+        # benchmark shape one side is all matrix-free rows and the other all explicit-Gram rows
+        if c_s and not c_m:
+            out.append(("als_short_kernel", sweep_bytes(nz, rows, F), t_s / c_s, c_s))
+        elif c_m and not c_s:
+            out.append(("als_gram_cg_kernel", sweep_bytes(nz, rows, F), t_m / c_m, c_m))
+        elif c_m and c_s:
+            frac = n_short / max(rows, 1)
+            out.append(("als_short_kernel", None, t_s / c_s, c_s))
+            out.append(("als_gram_cg_kernel", None, t_m / c_m, c_m))
+        return out
+
+    entries = [(tag, k, b, ms, n) for tag, csr, plan in (("user", eng.Cui_local, eng.plan_u), ("item", eng.Ciu_local, eng.plan_i))
+               for (k, b, ms, n) in side(tag, csr, plan)]
+    rl_all = []
+    for tag, k, b, ms, n in entries:
+        gbs = (b / (ms * 1e-3) / 1e9) if (b and ms > 0) else None
+        rl_all.append({"side": tag, "kernel": f"{k}<{F // 32}>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": None,
+                       "bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n})
+    dom = max(rl_all, key=lambda e: e["avg_launch_ms"]) if rl_all else None
+    roofline = dict(dom) if dom else None
+    kernel_ms = {k: v[0] / max(v[1], 1) for k, v in times.items()}
+
+    extra = {"setup_s": t_setup, "nnz": nnz, "kernel_ms_per_launch": kernel_ms, "half_sweep_rooflines": rl_all,
+             "iteration_GBps": (sweep_bytes(eng.Cui_local.nnz, eng.Cui_local.shape[0], F) +
+                                sweep_bytes(eng.Ciu_local.nnz, eng.Ciu_local.shape[0], F)) / s_per_iter / 1e9,
+             "user_short_rows": eng.plan_u.n_short_rows, "item_short_rows": eng.plan_i.n_short_rows,
+             "user_chunks": eng.plan_u.n_chunks, "item_chunks": eng.plan_i.n_chunks,
+             "item_split_rows": eng.plan_i.n_split_rows}
+
+    # ---- top-K pass for this rank's users (no exchange needed)
+    if not args.no_topk:
+        u0, u1 = drv.user_bounds[rank], drv.user_bounds[rank + 1]
+        W = E.factor_width(f, for_scoring=True)
+        Q = X[u0:u1] if W == F else X[u0:u1, :W].contiguous()
+        Ys = Y if W == F else Y[:, :W].contiguous()
+        mask = E.DeviceCSR(indptr, indices, data, (U, I)).row_slice(u0, u1)
+        E.topk(Q[:4096], Ys, args.topk, mask.row_slice(0, min(4096, u1 - u0)))
+        barrier()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            ids, scores = E.topk(Q, Ys, args.topk, mask)
+        barrier()
+        tk = (time.perf_counter() - t0) / reps
+        if world > 1:
+            t = torch.tensor([tk], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tk = float(t.item())
+        flops = 2.0 * (u1 - u0) * I * W
+        extra["top20_users_per_s"] = U / tk
+        extra["top20_pass_ms"] = tk * 1e3
+        extra["topk_roofline"] = {"kernel": f"topk_kernel<{W},4,2,64>", "bound": "mfma",
+                                  "achieved": flops / tk / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": flops / tk / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        del ids, scores
+
+    # ---- LightFM hybrid scoring (configs[4]): segment-sum + dot + top-20 for all users, rank 0's share
+    if not args.no_lightfm and rank == 0:
+        from movie_recommender_system_amd import LightFMScorer
+        nu_l = U // world
+        prob = synth.lightfm_problem(44, nu_l, I)
+        sc = LightFMScorer(prob["user_embeddings"], prob["user_biases"], prob["item_embeddings"], prob["item_biases"],
+                           device=dev)
+        sc.recommend(list(range(min(2048, nu_l))), prob["user_features"], prob["item_features"], args.topk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sc.recommend(None, prob["user_features"], prob["item_features"], args.topk)
+        torch.cuda.synchronize()
+        tl = time.perf_counter() - t0
+        extra["lightfm_top20_users_per_s_per_gpu_incl_transfers"] = nu_l / tl
+        del sc, prob
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(indptr.cpu().numpy(), indices.cpu().numpy(), (data * args.alpha).cpu().numpy(),
+                           Ciu.indptr.cpu().numpy(), Ciu.indices.cpu().numpy(), Ciu.data.cpu().numpy(),
+                           U, I, f, args.regularization, args.cpu_seconds, args.seed)
+        extra["speedup_vs_cpu_baseline"] = cpu["value"] / s_per_iter
+
+    if rank == 0:
+        out = {
+            "metric": "als_seconds_per_iteration", "value": s_per_iter, "unit": "s/iteration", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": s_per_iter * 1e3, "higher_is_better": False,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"implicit ALS (CG-3) f={f} fp32, {U} users x {I} movies, {nnz} interactions, "
+                                   f"alpha={args.alpha:g}, reg={args.regularization:g}; then top-{args.topk} for all users",
+                       "users": U, "items": I, "nnz": nnz, "factors": f, "sharding": f"rows-by-nnz x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,27 +66,36 @@ int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, 
  * steps, store X[u].  Rows without entries are set to zero.
  * Reference call sites: als/als.py:174, recommenders/als_recommender.py:136.
  *
- * A plan splits long rows into chunks of `chunk_nnz` stored entries so that
- * heavy rows spread over many workgroups; it depends only on `indptr` and can
+ * Two kernels share the rows.  Rows with at most `short_max` stored entries
+ * (empty rows included) are solved matrix-free, one wavefront per row, re-reading
+ * the gathered rows once per CG step (on chip for the first few of them,
+ * mirec_als_short_cache_rows(f)): the right form while the gathered table stays
+ * cache-resident.  Longer rows build A_u explicitly on the matrix cores; a
+ * plan splits them into chunks of `chunk_nnz` stored entries so that heavy
+ * rows spread over many workgroups.  The plan depends only on `indptr` and can
  * be reused for every iteration of a fit.
  *   nnz         stored entries in rows [row_begin, row_end)
  *   plan        device buffer of mirec_als_plan_bytes(nrows, nnz, chunk_nnz)
  *   chunk_nnz   in: requested chunk length, a multiple of 32 (0 = choose from
  *               nnz); out: the length used
+ *   short_max   >= 0; the same value must be given to the sweep (a negative
+ *               value there skips the matrix-free kernel: for profiling only)
  *   host_counts out: {number of chunks, number of split rows, number of
- *               partial-result slots}
+ *               partial-result slots, number of rows left to the matrix-free
+ *               kernel}
  * mirec_als_plan_build synchronises `stream` before it returns.  The sweep
  * takes the plan, `chunk_nnz` and `host_counts` exactly as the build left them
  * and a workspace of mirec_als_sweep_workspace_bytes(host_counts, f) bytes. */
+int mirec_als_short_cache_rows(int f);
 size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk_nnz);
 int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_end, int64_t nnz, int f,
-                         void* plan, size_t plan_bytes, int32_t* chunk_nnz, int64_t host_counts[3],
-                         mirec_stream_t stream);
-size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[3], int f);
+                         void* plan, size_t plan_bytes, int32_t* chunk_nnz, int32_t short_max,
+                         int64_t host_counts[4], mirec_stream_t stream);
+size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], int f);
 int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                          int64_t row_end, int64_t nnz, float* X, const float* Y, const float* G, int f,
-                         int cg_steps, const void* plan, int32_t chunk_nnz, const int64_t host_counts[3],
-                         void* ws, size_t ws_bytes, mirec_stream_t stream);
+                         int cg_steps, const void* plan, int32_t chunk_nnz, int32_t short_max,
+                         const int64_t host_counts[4], void* ws, size_t ws_bytes, mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * CSR transpose (`Ciu = Cui.T.tocsr()` inside implicit's fit; same call

@@ -1,0 +1,16 @@
+// Internal interfaces between the ALS translation units.
+#pragma once
+
+#include "common.h"
+
+namespace mirec {
+
+// Matrix-free wave-per-row solver for rows with at most short_max entries (als_short.hip).
+int launch_als_short(int nt, const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
+                     int64_t nrows, float* X, const float* Y, const float* G, int32_t short_max, int cg_steps,
+                     hipStream_t stream);
+
+// Gathered rows the matrix-free kernel can keep in LDS per CSR row at width 32*nt.
+int als_short_cache_rows(int nt);
+
+}  // namespace mirec

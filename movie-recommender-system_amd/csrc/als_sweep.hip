@@ -12,7 +12,7 @@
 // split over several chunks store their partial (A, b) to a workspace slot; a
 // second kernel sums the slots in chunk order (fixed, so results are
 // reproducible) and runs the same CG.
-#include "common.h"
+#include "als_internal.h"
 
 namespace mirec {
 
@@ -25,11 +25,12 @@ constexpr int TR = 32;  // gathered rows per LDS tile
 //   int32 mslot_ptr[nrows+1]   exclusive scan of (chunks if > 1 else 0)
 //   int32 multi_row[nrows+1]   row of every split row (first n_multi used)
 //   int32 scan scratch
+//   int32 counter              rows left to the matrix-free kernel
 //   int32 chunk_row[cap]       row of every chunk
 constexpr int SCAN_TILE = 2048;  // 256 threads x 8 items
 
 struct PlanLayout {
-    size_t chunk_ptr, multi_ptr, mslot_ptr, chunk_row, multi_row, scratch, total;
+    size_t chunk_ptr, multi_ptr, mslot_ptr, chunk_row, multi_row, scratch, counter, total;
     int64_t cap;
     int scan_blocks;
 };
@@ -54,20 +55,24 @@ static inline PlanLayout plan_layout(int64_t nrows, int64_t nnz, int32_t chunk_n
     L.mslot_ptr = off; off += arr;
     L.multi_row = off; off += arr;
     L.scratch = off;   off += align_up((size_t)L.scan_blocks * 4, 256);
+    L.counter = off;   off += 256;
     L.chunk_row = off; off += align_up((size_t)L.cap * 4, 256);
     L.total = off;
     return L;
 }
 
+// Rows with at most short_max entries (empty rows included) belong to the matrix-free kernel: no chunks.
 __global__ void plan_count_kernel(const int64_t* __restrict__ indptr, int64_t row_begin, int64_t nrows,
-                                  int32_t chunk_nnz, int32_t* chunk_ptr, int32_t* multi_ptr, int32_t* mslot_ptr) {
+                                  int32_t chunk_nnz, int32_t short_max, int32_t* chunk_ptr, int32_t* multi_ptr,
+                                  int32_t* mslot_ptr, int32_t* n_short) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nrows) return;
     int32_t nch = 0;
     if (r < nrows) {
         const int64_t nnz = indptr[row_begin + r + 1] - indptr[row_begin + r];
-        nch = nnz == 0 ? 1 : (int32_t)((nnz + chunk_nnz - 1) / chunk_nnz);
+        nch = nnz <= (int64_t)short_max ? 0 : (int32_t)((nnz + chunk_nnz - 1) / chunk_nnz);
     }
+    if (r < nrows && nch == 0) atomicAdd(n_short, 1);
     chunk_ptr[r] = nch;
     multi_ptr[r] = nch > 1 ? 1 : 0;
     mslot_ptr[r] = nch > 1 ? nch : 0;
@@ -442,13 +447,19 @@ extern "C" size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk
     return plan_layout(nrows, nnz, chunk_nnz).total;
 }
 
+extern "C" int mirec_als_short_cache_rows(int f) {
+    if (f % 32 != 0 || f < 32 || f > 192) return -1;
+    return als_short_cache_rows(f / 32);
+}
+
 extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_end, int64_t nnz, int f,
-                                    void* plan_, size_t plan_bytes, int32_t* chunk_nnz, int64_t host_counts[3],
-                                    mirec_stream_t stream_) {
+                                    void* plan_, size_t plan_bytes, int32_t* chunk_nnz, int32_t short_max,
+                                    int64_t host_counts[4], mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     (void)f;
     MIREC_REQUIRE(indptr && plan_ && chunk_nnz && host_counts, MIREC_E_INVALID, "mirec_als_plan_build: null argument");
     MIREC_REQUIRE(row_end >= row_begin && nnz >= 0, MIREC_E_INVALID, "mirec_als_plan_build: bad row range");
+    MIREC_REQUIRE(short_max >= 0, MIREC_E_INVALID, "mirec_als_plan_build: short_max must be >= 0");
     const int64_t nrows = row_end - row_begin;
     MIREC_REQUIRE(nrows < (int64_t)1 << 31, MIREC_E_UNSUPPORTED, "mirec_als_plan_build: more than 2^31 rows in one range");
     int32_t ch = *chunk_nnz;
@@ -463,8 +474,10 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
     int32_t* mslot_ptr = (int32_t*)(plan + L.mslot_ptr);
     int32_t* scratch = (int32_t*)(plan + L.scratch);
     const int64_t n1 = nrows + 1;
+    int32_t* n_short = (int32_t*)(plan + L.counter);
+    MIREC_HIP(hipMemsetAsync(n_short, 0, 256, stream));
     hipLaunchKernelGGL(plan_count_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream, indptr, row_begin,
-                       nrows, ch, chunk_ptr, multi_ptr, mslot_ptr);
+                       nrows, ch, short_max, chunk_ptr, multi_ptr, mslot_ptr, n_short);
     MIREC_LAUNCH_CHECK();
     int rc;
     if ((rc = exclusive_scan(chunk_ptr, n1, scratch, stream)) != MIREC_OK) return rc;
@@ -475,10 +488,11 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
                            chunk_ptr, multi_ptr, (int32_t*)(plan + L.chunk_row), (int32_t*)(plan + L.multi_row));
         MIREC_LAUNCH_CHECK();
     }
-    int32_t totals[3] = {0, 0, 0};
+    int32_t totals[4] = {0, 0, 0, 0};
     MIREC_HIP(hipMemcpyAsync(&totals[0], chunk_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
     MIREC_HIP(hipMemcpyAsync(&totals[1], multi_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
     MIREC_HIP(hipMemcpyAsync(&totals[2], mslot_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
+    MIREC_HIP(hipMemcpyAsync(&totals[3], n_short, 4, hipMemcpyDeviceToHost, stream));
     MIREC_HIP(hipStreamSynchronize(stream));
     MIREC_REQUIRE(totals[0] <= L.cap, MIREC_E_INVALID,
                   "mirec_als_plan_build: %d chunks exceed the plan capacity %lld (nnz argument too small?)", totals[0],
@@ -486,11 +500,12 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
     host_counts[0] = totals[0];
     host_counts[1] = totals[1];
     host_counts[2] = totals[2];
+    host_counts[3] = totals[3];
     *chunk_nnz = ch;
     return MIREC_OK;
 }
 
-extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[3], int f) {
+extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], int f) {
     if (!host_counts || f <= 0) return 0;
     const size_t slots = host_counts[2] > 0 ? (size_t)host_counts[2] : 1;
     return slots * ((size_t)f * f + f) * sizeof(float);
@@ -499,7 +514,8 @@ extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[3], 
 extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data,
                                     int64_t row_begin, int64_t row_end, int64_t nnz, float* X, const float* Y,
                                     const float* G, int f, int cg_steps, const void* plan, int32_t chunk_nnz,
-                                    const int64_t host_counts[3], void* ws, size_t ws_bytes, mirec_stream_t stream_) {
+                                    int32_t short_max, const int64_t host_counts[4], void* ws, size_t ws_bytes,
+                                    mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MIREC_REQUIRE(indptr && X && Y && G && plan && host_counts, MIREC_E_INVALID, "mirec_als_half_sweep: null argument");
     MIREC_REQUIRE(nnz == 0 || (indices && data), MIREC_E_INVALID, "mirec_als_half_sweep: null indices/data");
@@ -518,6 +534,12 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     const PlanLayout L = plan_layout(nrows, nnz, chunk_nnz);
     const char* p = (const char*)plan;
     float* partials = (float*)ws;
+    if (short_max >= 0 && host_counts[3] > 0) {
+        const int rc = launch_als_short(f / 32, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps,
+                                        stream);
+        if (rc != MIREC_OK) return rc;
+    }
+    if (host_counts[0] == 0 && host_counts[1] == 0) return MIREC_OK;
     switch (f / 32) {
         case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
         case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);

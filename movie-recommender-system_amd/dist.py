@@ -86,7 +86,7 @@ class ShardedAlsDriver:
 
 
 def gpu_driver(Cui, Ciu, X: torch.Tensor, Y: torch.Tensor, regularization: float, cg_steps: int, rank: int,
-               world: int, group=None, chunk_nnz: int = 0):
+               world: int, group=None, chunk_nnz: int = 0, short_max=None):
     """Build the libmirec engine of this rank's shard and the driver around it.
     `Cui` / `Ciu` are whole `engine.DeviceCSR` matrices on this rank's GPU."""
     from . import engine as E
@@ -96,6 +96,6 @@ def gpu_driver(Cui, Ciu, X: torch.Tensor, Y: torch.Tensor, regularization: float
     ub = partition_rows(Cui.indptr, world)
     ib = partition_rows(Ciu.indptr, world)
     eng = E.AlsEngine(Cui, Ciu, X, Y, regularization, cg_steps, user_rows=(ub[rank], ub[rank + 1]),
-                      item_rows=(ib[rank], ib[rank + 1]), chunk_nnz=chunk_nnz)
+                      item_rows=(ib[rank], ib[rank + 1]), chunk_nnz=chunk_nnz, short_max=short_max)
     drv = ShardedAlsDriver(X, Y, ub, ib, lambda a, b: eng.user_sweep(), lambda a, b: eng.item_sweep(), rank, group)
     return drv, eng

@@ -119,21 +119,36 @@ def gram(Y: torch.Tensor, reg: float, out: Optional[torch.Tensor] = None, ws: Op
     return out
 
 
-class SweepPlan:
-    """Chunk plan of one CSR row range for a given factor width."""
+# The matrix-free kernel re-reads a row's gathered factor rows on every CG step.  That is cheap while the
+# gathered table sits in L2 / Infinity Cache and a 4x HBM bill once it does not, so rows of any length go
+# to it only below this table size; above it only rows that fit its LDS cache do.
+SHORT_TABLE_BYTES = 96 << 20
+ALL_ROWS = (1 << 31) - 1
 
-    def __init__(self, csr: DeviceCSR, f: int, chunk_nnz: int = 0):
+
+class SweepPlan:
+    """Chunk plan of one CSR row range for a given factor width.
+
+    ``short_max``: rows with at most this many stored entries are solved by the
+    matrix-free wave-per-row kernel, the others by the explicit-Gram kernel
+    (None = choose from the size of the gathered table)."""
+
+    def __init__(self, csr: DeviceCSR, f: int, chunk_nnz: int = 0, short_max: Optional[int] = None):
         lib = _lib.require()
         self.csr, self.f = csr, int(f)
         nrows = csr.shape[0]
         dev = csr.indptr.device
+        if short_max is None:
+            table_bytes = csr.shape[1] * self.f * 4
+            short_max = ALL_ROWS if table_bytes <= SHORT_TABLE_BYTES else max(lib.mirec_als_short_cache_rows(self.f), 0)
+        self.short_max = int(short_max)
         nbytes = lib.mirec_als_plan_bytes(nrows, csr.nnz, int(chunk_nnz))
         self.plan = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
         chunk = ctypes.c_int32(int(chunk_nnz))
-        self.counts = (ctypes.c_int64 * 3)()
+        self.counts = (ctypes.c_int64 * 4)()
         _lib.check(lib.mirec_als_plan_build(_ptr(csr.indptr), 0, nrows, csr.nnz, self.f, _ptr(self.plan),
-                                            self.plan.numel(), ctypes.byref(chunk), self.counts, _stream_ptr()),
-                   "mirec_als_plan_build")
+                                            self.plan.numel(), ctypes.byref(chunk), self.short_max, self.counts,
+                                            _stream_ptr()), "mirec_als_plan_build")
         self.chunk_nnz = int(chunk.value)
         ws_bytes = lib.mirec_als_sweep_workspace_bytes(self.counts, self.f)
         self.ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)
@@ -146,16 +161,31 @@ class SweepPlan:
     def n_split_rows(self) -> int:
         return int(self.counts[1])
 
-    def sweep(self, X_rows: torch.Tensor, Y: torch.Tensor, G: torch.Tensor, cg_steps: int = 3) -> None:
+    @property
+    def n_short_rows(self) -> int:
+        return int(self.counts[3])
+
+    def sweep(self, X_rows: torch.Tensor, Y: torch.Tensor, G: torch.Tensor, cg_steps: int = 3,
+              phase: str = "both") -> None:
         """Solve the plan's rows in place: ``X_rows`` is the [nrows, f] block of
-        the factor matrix that belongs to these CSR rows."""
+        the factor matrix that belongs to these CSR rows.  ``phase`` lets a
+        profiler bracket the kernels of a sweep separately: "short" launches
+        only the matrix-free kernel, "main" only the Gram+CG kernel, "finalize"
+        only the split-row reduction (which must follow "main" on the stream)."""
         lib = _lib.require()
         csr = self.csr
         assert X_rows.shape == (csr.shape[0], self.f) and X_rows.is_contiguous()
         assert Y.shape[1] == self.f and Y.is_contiguous() and Y.shape[0] >= csr.shape[1]
+        counts, short_max = self.counts, self.short_max
+        if phase != "both":
+            counts = (ctypes.c_int64 * 4)(self.counts[0] if phase == "main" else 0,
+                                          self.counts[1] if phase == "finalize" else 0, self.counts[2],
+                                          self.counts[3] if phase == "short" else 0)
+            if phase != "short":
+                short_max = -1
         _lib.check(lib.mirec_als_half_sweep(_ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.data), 0, csr.shape[0],
                                             csr.nnz, _ptr(X_rows), _ptr(Y), _ptr(G), self.f, int(cg_steps),
-                                            _ptr(self.plan), self.chunk_nnz, self.counts, _ptr(self.ws),
+                                            _ptr(self.plan), self.chunk_nnz, short_max, counts, _ptr(self.ws),
                                             self.ws.numel(), _stream_ptr()), "mirec_als_half_sweep")
 
 
@@ -168,7 +198,7 @@ class AlsEngine:
 
     def __init__(self, Cui: DeviceCSR, Ciu: Optional[DeviceCSR], X: torch.Tensor, Y: torch.Tensor,
                  regularization: float, cg_steps: int = 3, user_rows: Optional[Tuple[int, int]] = None,
-                 item_rows: Optional[Tuple[int, int]] = None, chunk_nnz: int = 0):
+                 item_rows: Optional[Tuple[int, int]] = None, chunk_nnz: int = 0, short_max: Optional[int] = None):
         self.f = int(X.shape[1])
         assert Y.shape[1] == self.f
         self.X, self.Y = X, Y
@@ -181,26 +211,60 @@ class AlsEngine:
         cu = Cui if self.user_rows == (0, users) else Cui.row_slice(*self.user_rows)
         ci = Ciu if self.item_rows == (0, items) else Ciu.row_slice(*self.item_rows)
         self.Cui_local, self.Ciu_local = cu, ci
-        self.plan_u = SweepPlan(cu, self.f, chunk_nnz)
-        self.plan_i = SweepPlan(ci, self.f, chunk_nnz)
+        self.plan_u = SweepPlan(cu, self.f, chunk_nnz, short_max)
+        self.plan_i = SweepPlan(ci, self.f, chunk_nnz, short_max)
         lib = _lib.require()
         need = max(lib.mirec_gram_workspace_bytes(users, self.f), lib.mirec_gram_workspace_bytes(items, self.f))
         self.gram_ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=X.device)
         self.G = torch.empty((self.f, self.f), dtype=torch.float32, device=X.device)
 
+    # Every launch goes through _run so that a benchmark can bracket each kernel
+    # with events on the launching stream (self.events = [] switches it on).
+    events = None
+
+    def _run(self, name: str, fn) -> None:
+        if self.events is None:
+            fn()
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.events.append((name, a, b))
+
+    def _sweep(self, tag: str, plan: "SweepPlan", rows: torch.Tensor, other: torch.Tensor) -> None:
+        if self.events is None:
+            plan.sweep(rows, other, self.G, self.cg_steps)
+            return
+        if plan.n_short_rows:
+            self._run(tag + "_short", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "short"))
+        if plan.n_chunks:
+            self._run(tag + "_main", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "main"))
+        if plan.n_split_rows:
+            self._run(tag + "_finalize", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "finalize"))
+
     def user_sweep(self) -> None:
-        gram(self.Y, self.reg, self.G, self.gram_ws)
+        self._run("gram_items", lambda: gram(self.Y, self.reg, self.G, self.gram_ws))
         u0, u1 = self.user_rows
-        self.plan_u.sweep(self.X[u0:u1], self.Y, self.G, self.cg_steps)
+        self._sweep("user", self.plan_u, self.X[u0:u1], self.Y)
 
     def item_sweep(self) -> None:
-        gram(self.X, self.reg, self.G, self.gram_ws)
+        self._run("gram_users", lambda: gram(self.X, self.reg, self.G, self.gram_ws))
         i0, i1 = self.item_rows
-        self.plan_i.sweep(self.Y[i0:i1], self.X, self.G, self.cg_steps)
+        self._sweep("item", self.plan_i, self.Y[i0:i1], self.X)
 
     def iteration(self) -> None:
         self.user_sweep()
         self.item_sweep()
+
+    def event_times_ms(self) -> dict:
+        """Sum and count of the recorded intervals per kernel name (call after a
+        synchronize)."""
+        out = {}
+        for name, a, b in self.events or []:
+            t, n = out.get(name, (0.0, 0))
+            out[name] = (t + a.elapsed_time(b), n + 1)
+        return out
 
 
 def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = None,
