@@ -1,0 +1,188 @@
+"""Host-side logic without a GPU: the C ABI loads and exports what the header
+declares, the artefact layout round-trips, the plugin behaves like the
+reference's (src/shrekommender_system/tests/test_als_recommender.py:35-84, but
+against real objects instead of mocks), and the product path refuses to run
+without a device."""
+
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from movie_recommender_system_amd import ALSRecommender, AlternatingLeastSquares, LightFMScorer, _lib, artifacts
+from movie_recommender_system_amd.base import ModelNotLoadedException
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mirec.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(mirec_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.mirec_version() >= 100
+    assert lib.mirec_factor_width(2, 0) == 32 and lib.mirec_factor_width(100, 0) == 128
+    assert lib.mirec_factor_width(17, 1) == 24 and lib.mirec_factor_width(193, 0) == -1
+    assert lib.mirec_als_short_cache_rows(128) == 22 and lib.mirec_als_short_cache_rows(100) == -1
+
+
+def test_abi_rejects_bad_arguments_without_touching_a_device():
+    lib = _lib.load()
+    rc = lib.mirec_topk(None, 4, None, 4, 20, None, None, None, None, 0, None, None, None)
+    assert rc == -1 and "k must be" in _lib.last_error()
+    rc = lib.mirec_topk(None, 4, None, 4, 20, None, None, None, None, 500, None, None, None)
+    assert rc == -4 and "224" in _lib.last_error()
+    rc = lib.mirec_gram(None, 10, 50, 0.1, None, None, 0, None)
+    assert rc != 0
+    with pytest.raises(_lib.MirecError):
+        _lib.check(rc, "mirec_gram")
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-device failure mode")
+def test_numeric_calls_fail_loudly_without_a_gpu():
+    M = sp.csr_matrix(np.array([[1, 0, 1], [0, 1, 0]], dtype=np.float32))
+    model = AlternatingLeastSquares(factors=2, iterations=1, random_state=42)
+    with pytest.raises(_lib.MirecError, match="no HIP device"):
+        model.fit(M)
+    sc = LightFMScorer(np.zeros((3, 2)), np.zeros(3), np.zeros((4, 2)), np.zeros(4))
+    with pytest.raises(_lib.MirecError):
+        sc.predict(np.array([0]), np.array([1]))
+
+
+def test_build_matrix_matches_reference_semantics():
+    """als/als.py:107-123: ids as strings in lexicographic order, duplicates collapse, values 1.0 fp32."""
+    users = [10, 9, 10, "a", 9, 10]
+    movies = ["m2", "m1", "m2", "m1", "m10", "m1"]
+    M, u2i, m2i, i2m = artifacts.build_matrix(users, movies)
+    assert list(u2i) == ["10", "9", "a"] and list(m2i) == ["m1", "m10", "m2"]
+    assert M.dtype == np.float32 and M.shape == (3, 3) and M.nnz == 5
+    assert M.toarray().tolist() == [[1, 0, 1], [1, 1, 0], [1, 0, 0]]
+    assert i2m[2] == "m2"
+
+
+def test_popularity_conventions():
+    M = sp.csr_matrix(np.array([[1, 1, 0, 1], [1, 0, 0, 1], [1, 0, 0, 0]], dtype=np.float32))
+    a = artifacts.popularity_order(M, "sort_then_reverse")     # als_recommender.py:138-139
+    b = artifacts.popularity_order(M, "negate_then_sort")      # als/als.py:175-176
+    sums = np.asarray(M.sum(axis=0)).ravel()
+    assert np.array_equal(a, np.argsort(sums)[::-1]) and np.array_equal(b, np.argsort(-sums))
+    assert a[0] == 0 and b[0] == 0 and set(a[-2:].tolist()) == {1, 2}
+
+
+@pytest.fixture
+def dummy_artefacts():
+    train_matrix = sp.csr_matrix(np.array([[1, 0, 1], [0, 1, 0]], dtype=np.float32))
+    return {
+        "train_matrix": train_matrix,
+        "user_mappings": {"user_to_idx": {"u1": 0, "u2": 1}, "n_users": 2},
+        "movie_mappings": {"idx_to_movie": {0: "m1", 1: "m2", 2: "m3"}, "movie_to_idx": {"m1": 0, "m2": 1, "m3": 2},
+                           "n_movies": 3},
+    }
+
+
+def loaded_plugin(dummy_artefacts):
+    """A plugin in the state `train` leaves it in, with fixed factors instead of a GPU fit."""
+    rec = ALSRecommender({"artefacts": {}, "metadata": {}}, "als")
+    rec.train_matrix = dummy_artefacts["train_matrix"]
+    rec.user_mappings = dummy_artefacts["user_mappings"]
+    rec.movie_mappings = dummy_artefacts["movie_mappings"]
+    model = AlternatingLeastSquares(factors=2, iterations=1, alpha=40, random_state=42)
+    model.user_factors = np.array([[1.0, 0.0], [0.0, 1.0]], dtype=np.float32)
+    model.item_factors = np.array([[1.0, 0.0], [0.5, 0.5], [0.0, 1.0]], dtype=np.float32)
+    rec.model = model
+    rec.most_popular_movies = artifacts.popularity_order(rec.train_matrix)
+    rec.hyperparameters = {"factors": 2, "iterations": 1}
+    rec.is_loaded = True
+    return rec
+
+
+def test_plugin_not_loaded(dummy_artefacts):
+    rec = ALSRecommender({"artefacts": dummy_artefacts, "hyperparameters": {"factors": 2, "iterations": 1}})
+    with pytest.raises(ModelNotLoadedException):
+        rec.recommend_for_user("u1")
+    with pytest.raises(ModelNotLoadedException):
+        rec.get_model_stats()
+    assert rec.health_check()["status"] == "unhealthy"
+    with pytest.raises(ValueError, match="Missing required artefact"):
+        rec.train({"artefacts": {"train_matrix": dummy_artefacts["train_matrix"]}})
+
+
+def test_plugin_new_user_profile_stats_and_fallback(dummy_artefacts):
+    rec = loaded_plugin(dummy_artefacts)
+    new = rec.recommend_for_user("new_user", N=2)
+    assert new.user_type == "new" and new.method == "most_popular" and new.total_count == 2
+    assert [r["rank"] for r in new.recommendations] == [1, 2] and new.recommendations[0]["score"] is None
+    assert new.to_dict()["model_name"] == "als"
+    prof = rec.get_user_profile("u1")
+    assert prof["user_type"] == "known" and prof["interactions_count"] == 2 and prof["liked_movies"] == ["m1", "m3"]
+    assert rec.get_user_profile("nobody")["interactions_count"] == 0
+    stats = rec.get_model_stats()
+    assert stats["n_users"] == 2 and stats["n_movies"] == 3 and stats["matrix_shape"] == (2, 3)
+    assert stats["n_interactions"] == 3 and stats["sparsity"] == pytest.approx(50.0)
+    assert rec.health_check()["status"] == "healthy"
+    unknown = rec.get_similar_items("mX")
+    assert unknown.error is not None and unknown.total_count == 0
+    if NO_GPU:
+        # scoring raises (no device) -> the reference's contract: log and serve the popular list
+        known = rec.recommend_for_user("u1", N=2)
+        assert known.user_type == "new" and known.total_count == 2
+        sim = rec.get_similar_items("m1", N=2)
+        assert sim.error is not None and sim.similar_items == []
+
+
+def test_save_load_roundtrip_and_artifact_layout(tmp_path, dummy_artefacts):
+    rec = loaded_plugin(dummy_artefacts)
+    rec.save_model(str(tmp_path / "only_model"))
+    blob = pickle.load(open(tmp_path / "only_model" / "als_model.pkl", "rb"))
+    assert set(blob) >= {"model", "most_popular_movies", "model_params"}
+    # the full models/als@v1 layout
+    root = artifacts.write_artifacts(tmp_path / "als@v1", rec.train_matrix, rec.user_mappings["user_to_idx"],
+                                     rec.movie_mappings["movie_to_idx"], rec.model,
+                                     metadata={"trained_at": "2026-01-01T00:00:00Z"})
+    assert sorted(os.listdir(root)) == ["als_model.pkl", "dataset_stats.json", "manifest.yaml", "movie_mappings.pkl",
+                                        "train_matrix.npz", "user_mappings.pkl"]
+    import yaml
+    manifest = yaml.safe_load(open(root / "manifest.yaml"))
+    assert {"name", "version", "class_path", "runtime", "artefacts", "metadata"} <= set(manifest)
+    assert manifest["class_path"] == "movie_recommender_system_amd.recommender:ALSRecommender"
+    # resolve the class_path the way the reference's registry does (serving/model_registry.py:109-118)
+    module_name, cls_name = manifest["class_path"].split(":")
+    cls = getattr(__import__(module_name, fromlist=[cls_name]), cls_name)
+    config = {**manifest["runtime"], "artefacts": manifest["artefacts"], "metadata": manifest["metadata"]}
+    fresh = cls(config, "als@v1")
+    fresh.load_model(str(root))
+    assert fresh.is_loaded and fresh.user_mappings["n_users"] == 2 and fresh.movie_mappings["n_movies"] == 3
+    assert np.array_equal(fresh.model.item_factors, rec.model.item_factors)
+    assert fresh.model.factors == 2 and fresh.model.alpha == 40.0
+    assert np.array_equal(fresh.most_popular_movies, rec.most_popular_movies)
+    assert fresh.recommend_for_user("stranger", 3).total_count == 3
+    # both mapping styles are present (als/als.py:149-153 and als_recommender.py:85-86)
+    um = pickle.load(open(root / "user_mappings.pkl", "rb"))
+    assert {"user_to_idx", "idx_to_user", "n_users"} <= set(um)
+    state = pickle.load(open(root / "als_model.pkl", "rb"))["model_state"]
+    assert state["factors"] == 2 and state["user_factors"].shape == (2, 2)
+    fresh.teardown()
+    assert fresh.model is None and not fresh.is_loaded
+    with pytest.raises(FileNotFoundError):
+        cls(config, "x").load_model(str(tmp_path / "missing"))
+
+
+def test_model_state_is_plain_numpy():
+    model = AlternatingLeastSquares(factors=3, regularization=0.5, alpha=2.0, iterations=7, random_state=9)
+    model.user_factors = np.ones((2, 3), dtype=np.float32)
+    model.item_factors = np.zeros((4, 3), dtype=np.float32)
+    clone = pickle.loads(pickle.dumps(model))
+    assert clone.factors == 3 and clone.regularization == 0.5 and clone.iterations == 7 and clone.random_state == 9
+    assert np.array_equal(clone.user_factors, model.user_factors)
+    assert clone.item_norms.tolist() == [1e-10] * 4 or np.allclose(clone.item_norms, 1e-10)
+    with pytest.raises(NotImplementedError):
+        AlternatingLeastSquares(use_cg=False)
