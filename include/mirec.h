@@ -76,8 +76,8 @@ int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, 
  * be reused for every iteration of a fit.
  *   nnz         stored entries in rows [row_begin, row_end)
  *   plan        device buffer of mirec_als_plan_bytes(nrows, nnz, chunk_nnz)
- *   chunk_nnz   in: requested chunk length, a multiple of 32 (0 = choose from
- *               nnz); out: the length used
+ *   chunk_nnz   in: rows with more stored entries than this are split (into at
+ *               most 32 equal chunks); 0 = choose from nnz; out: the value used
  *   short_max   >= 0; the same value must be given to the sweep (a negative
  *               value there skips the matrix-free kernel: for profiling only)
  *   host_counts out: {number of chunks, number of split rows, number of
@@ -118,7 +118,8 @@ int mirec_csr_transpose(const int64_t* indptr, const int32_t* indices, const flo
  * Reference call sites: recommenders/als_recommender.py:181-186 (recommend,
  * filter_already_liked_items=True), :237 (similar_items),
  * hybrid_docker/inference.py:197 (argsort top-k, via mirec_lightfm_*).
- * mask_indptr may be null (no filter); it is indexed by query row. */
+ * mask_indptr may be null (no filter); it is indexed by query row, and every
+ * mask row must list its items in ascending order. */
 int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, int f, const int64_t* mask_indptr,
                const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
                float* out_scores, mirec_stream_t stream);

@@ -1,11 +1,14 @@
-// ALS half-sweep: per-row confidence-weighted Gram on the fp32 matrix cores,
-// then a warm-started conjugate-gradient solve (3 steps by default).
+// ALS half-sweep, explicit form: per-row confidence-weighted Gram on the fp32
+// matrix cores, then a warm-started conjugate-gradient solve (3 steps by default).
 //
-// Work unit = one "chunk": up to chunk_nnz stored entries of one CSR row.  A
-// workgroup of NT wavefronts (F = 32*NT factor columns) gathers the chunk's
-// factor rows 32 at a time through a double-buffered LDS tile and accumulates
-//     A += sum_k (|c_k|-1) y_k y_k^T      (v_mfma_f32_32x32x2_f32, wave w owns
-//                                          the 32-row band w of A)
+// Work unit = one "chunk": a run of stored entries of one CSR row (rows longer
+// than chunk_nnz are cut into up to 32 equal chunks).  A workgroup of NT
+// wavefronts (F = 32*NT factor columns) gathers the chunk's factor rows 64 at a
+// time through a double-buffered LDS tile -- the next tile's gathers and the
+// indices of the one after are in flight while the current one is consumed --
+// and accumulates
+//     A += sum_k (|c_k|-1) y_k y_k^T      (v_mfma_f32_16x16x4_f32, only the
+//                                          tiles on or above the diagonal)
 //     b += sum_k max(c_k,0) y_k
 // Rows that fit one chunk are finished in the same workgroup: A + G is written
 // to LDS (aliasing the gather tiles) and wave 0 runs the CG steps on it.  Rows
@@ -16,7 +19,8 @@
 
 namespace mirec {
 
-constexpr int TR = 32;  // gathered rows per LDS tile
+constexpr int TR = 64;               // gathered rows per LDS tile
+constexpr int MAX_ROW_CHUNKS = 32;   // a row is split into at most this many chunks
 
 // ---------------------------------------------------------------- plan -----
 // Device layout of a plan for `nrows` rows and at most `cap` chunks:
@@ -71,6 +75,7 @@ __global__ void plan_count_kernel(const int64_t* __restrict__ indptr, int64_t ro
     if (r < nrows) {
         const int64_t nnz = indptr[row_begin + r + 1] - indptr[row_begin + r];
         nch = nnz <= (int64_t)short_max ? 0 : (int32_t)((nnz + chunk_nnz - 1) / chunk_nnz);
+        if (nch > MAX_ROW_CHUNKS) nch = MAX_ROW_CHUNKS;
     }
     if (r < nrows && nch == 0) atomicAdd(n_short, 1);
     chunk_ptr[r] = nch;
@@ -148,49 +153,6 @@ static int exclusive_scan(int32_t* data, int64_t n, int32_t* scratch, hipStream_
     return MIREC_OK;
 }
 
-// ------------------------------------------------------------- kernels -----
-struct Staged {
-    float4 v[4];
-    float2 wc;
-};
-
-template <int NT>
-__device__ __forceinline__ void load_tile(Staged& st, const int32_t* __restrict__ indices,
-                                          const float* __restrict__ data, const float* __restrict__ Y, int64_t k0,
-                                          int64_t ke, int tid) {
-    constexpr int F = 32 * NT;
-    const int c4 = tid % (8 * NT);
-    const int rsub = tid / (8 * NT);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int64_t k = k0 + p * 8 + rsub;
-        if (k < ke) {
-            const int32_t idx = indices[k];
-            st.v[p] = *reinterpret_cast<const float4*>(Y + (int64_t)idx * F + 4 * c4);
-        } else {
-            st.v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    st.wc = make_float2(0.f, 0.f);
-    if (tid < TR) {
-        const int64_t k = k0 + tid;
-        if (k < ke) {
-            const float c = data[k];
-            st.wc = make_float2(fabsf(c) - 1.f, c > 0.f ? c : 0.f);
-        }
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void store_tile(const Staged& st, float* tile, float2* wts, int tid) {
-    constexpr int F = 32 * NT;
-    const int c4 = tid % (8 * NT);
-    const int rsub = tid / (8 * NT);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(tile + (p * 8 + rsub) * F + 4 * c4) = st.v[p];
-    if (tid < TR) wts[tid] = st.wc;
-}
-
 // out = A v for the symmetric LDS matrix A; lane holds columns lane + 64*m.
 template <int F>
 __device__ __forceinline__ void symv_wave(const float* A, float* vec, const float (&v)[(F + 63) / 64],
@@ -207,6 +169,7 @@ __device__ __forceinline__ void symv_wave(const float* A, float* vec, const floa
     int colc[NC];
 #pragma unroll
     for (int m = 0; m < NC; ++m) colc[m] = (lane + 64 * m < F) ? lane + 64 * m : F - 1;
+#pragma unroll 2
     for (int k = 0; k < F; k += 4) {
         const float4 pk = *reinterpret_cast<const float4*>(vec + k);
 #pragma unroll
@@ -271,34 +234,221 @@ __device__ void cg_solve_wave(const float* A, const float* b, float* vec, float*
     }
 }
 
+// ------------------------------------------------------------- kernels -----
+// Geometry of the explicit-Gram kernel at width F = 32*NT:
+//   A_u is cut into 16x16 tiles; only the NB(NB+1)/2 tiles on or above the
+//   diagonal are accumulated (NB = F/16 bands).  Wave w of the NT waves owns
+//   band-rows w and NB-1-w: (NB-w) + (w+1) = NB+1 tiles each, so the matrix
+//   pipes of the four SIMDs are evenly loaded.
+//   Gathered rows are staged 64 at a time in LDS with a row stride of F+16
+//   floats, which puts the four rows of one MFMA k-step on disjoint banks.
 template <int NT>
-struct SweepLds {
+struct GramCfg {
     static constexpr int F = 32 * NT;
-    static constexpr int BIGN = (F * F > 2 * TR * F) ? F * F : 2 * TR * F;
-    static constexpr int FLOATS = BIGN + 2 * 2 * TR + 2 * F;
+    static constexpr int NB = 2 * NT;
+    static constexpr int LDF = F + 16;
+    static constexpr int NTHR = 64 * NT;
+    static constexpr int NTILES = NB * (NB + 1) / 2;
+    static constexpr int TILE_FLOATS = TR * LDF;
+    static constexpr int BIGN = (F * F > 2 * TILE_FLOATS) ? F * F : 2 * TILE_FLOATS;
+    static constexpr int PART_STRIDE = NTILES * 256 + F;  // floats of one partial-result slot
+    static constexpr int FLOATS = BIGN + 2 * TR * 2 + 2 * F;
     static constexpr size_t BYTES = (size_t)FLOATS * 4;
+    // first tile id of band-row b in the row-major enumeration of the upper triangle
+    static constexpr int row_start(int b) { return b * NB - b * (b - 1) / 2; }
 };
+
+constexpr int RPT = TR / 8;  // gathered rows per thread per tile (8 rows per pass of the workgroup)
+
+// Accumulators of wave W: band-row W (tiles (W, W..NB-1)) and band-row NB-1-W (tiles (R1, R1..NB-1)).
+template <int NT, int W>
+struct WaveAcc {
+    static constexpr int NB = 2 * NT;
+    static constexpr int R1 = NB - 1 - W;
+    static constexpr int N0 = NB - W;
+    static constexpr int N1 = W + 1;
+    f32x4 a0[N0];
+    f32x4 a1[N1];
+    float b0, b1;
+};
+
+// One LDS tile of 64 gathered rows: 16 k-steps of v_mfma_f32_16x16x4_f32.  Lane l feeds row 4s + (l>>4)
+// of the step and column (l&15) of each band.  Operands of step s+1 are read while step s's MFMAs run.
+template <int NT, int W>
+__device__ __forceinline__ void gram_tile(const float* tl, const float2* wt, WaveAcc<NT, W>& A, int lane) {
+    using C = GramCfg<NT>;
+    using WA = WaveAcc<NT, W>;
+    constexpr int N0 = WA::N0, N1 = WA::N1, R1 = WA::R1;
+    const int q = lane >> 4, i = lane & 15;
+    const float* base = tl + q * C::LDF + W * 16 + i;
+    float bq[2][N0];
+    float2 wq[2];
+#pragma unroll
+    for (int j = 0; j < N0; ++j) bq[0][j] = base[j * 16];
+    wq[0] = wt[q];
+#pragma unroll
+    for (int s = 0; s < TR / 4; ++s) {
+        if (s + 1 < TR / 4) {
+            const float* nb = base + (s + 1) * 4 * C::LDF;
+#pragma unroll
+            for (int j = 0; j < N0; ++j) bq[(s + 1) & 1][j] = nb[j * 16];
+            wq[(s + 1) & 1] = wt[(s + 1) * 4 + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float(&b)[N0] = bq[s & 1];
+        const float2 wc = wq[s & 1];
+        const float a0 = b[0] * wc.x;
+        const float a1 = b[R1 - W] * wc.x;
+#pragma unroll
+        for (int j = 0; j < N0; ++j) A.a0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], A.a0[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < N1; ++j) A.a1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[R1 - W + j], A.a1[j], 0, 0, 0);
+        A.b0 = fmaf(wc.y, b[0], A.b0);
+        A.b1 = fmaf(wc.y, b[R1 - W], A.b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Everything a wave does for one chunk once its wave index is a compile-time constant.
+template <int NT, int W>
+__device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indices, const float* __restrict__ data,
+                                                const float* __restrict__ Y, const float* __restrict__ G, int64_t ks,
+                                                int64_t ke, float* smem, bool single, float* P, int tid, int lane) {
+    using C = GramCfg<NT>;
+    using WA = WaveAcc<NT, W>;
+    constexpr int F = C::F;
+    float* big = smem;
+    float2* wts = reinterpret_cast<float2*>(smem + C::BIGN);
+    float* bvec = smem + C::BIGN + 2 * TR * 2;
+
+    WA A;
+#pragma unroll
+    for (int j = 0; j < WA::N0; ++j) A.a0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < WA::N1; ++j) A.a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    A.b0 = 0.f;
+    A.b1 = 0.f;
+
+    // Staging registers of this thread: RPT gathered rows (one float4 column group each), their indices one
+    // tile further ahead, and the confidence of tile row `tid`.  Index loads are unconditional (clamped to
+    // the chunk's last entry): rows past the end get weight 0.  The confidence stays raw until store time so
+    // that nothing waits on its load while the gathers behind it are in flight.
+    const int ntiles = (int)((ke - ks + TR - 1) / TR);
+    const int c4 = tid % (8 * NT);
+    const int rsub = tid / (8 * NT);
+    int idx[RPT];
+    f32x4 sv[RPT];
+    float craw = 0.f;
+    bool cvalid = false;
+    auto load_idx = [&](int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < RPT; ++p) {
+            const int64_t k = k0 + p * 8 + rsub;
+            idx[p] = indices[k < ke ? k : ke - 1];
+        }
+    };
+    auto load_rows = [&](int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < RPT; ++p) sv[p] = *reinterpret_cast<const f32x4*>(Y + (int64_t)idx[p] * F + 4 * c4);
+        if (tid < TR) {
+            const int64_t k = k0 + tid;
+            craw = data[k < ke ? k : ke - 1];
+            cvalid = k < ke;
+        }
+    };
+    auto store_tile = [&](float* tile, float2* wt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < RPT; ++p) *reinterpret_cast<f32x4*>(tile + (p * 8 + rsub) * C::LDF + 4 * c4) = sv[p];
+        if (tid < TR)
+            wt[tid] = cvalid ? make_float2(fabsf(craw) - 1.f, craw > 0.f ? craw : 0.f) : make_float2(0.f, 0.f);
+    };
+
+    load_idx(ks);
+    load_rows(ks);
+    if (ntiles > 1) load_idx(ks + TR);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        float* tl = big + (tile & 1) * C::TILE_FLOATS;
+        float2* wt = wts + (tile & 1) * TR;
+        store_tile(tl, wt);
+        __syncthreads();
+        // gathers of the next tile (their indices arrived a tile ago), then the indices of the one after
+        if (tile + 1 < ntiles) load_rows(ks + (int64_t)(tile + 1) * TR);
+        if (tile + 2 < ntiles) load_idx(ks + (int64_t)(tile + 2) * TR);
+        __builtin_amdgcn_sched_barrier(0);
+        gram_tile<NT, W>(tl, wt, A, lane);
+    }
+    // column sums of the b partials over the four row groups of a k-step
+    float b0 = A.b0, b1 = A.b1;
+    b0 += __shfl_xor(b0, 16, 64);
+    b0 += __shfl_xor(b0, 32, 64);
+    b1 += __shfl_xor(b1, 16, 64);
+    b1 += __shfl_xor(b1, 32, 64);
+    __syncthreads();  // every wave is done with the gather tiles that alias `big`
+
+    const int q = lane >> 4, i = lane & 15;
+    if (single) {
+        // A + G into LDS, both triangles
+#pragma unroll
+        for (int j = 0; j < WA::N0; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = W * 16 + q * 4 + e, cc = (W + j) * 16 + i;
+                const float v = A.a0[j][e];
+                big[rr * F + cc] = v + G[rr * F + cc];
+                if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
+            }
+#pragma unroll
+        for (int j = 0; j < WA::N1; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = WA::R1 * 16 + q * 4 + e, cc = (WA::R1 + j) * 16 + i;
+                const float v = A.a1[j][e];
+                big[rr * F + cc] = v + G[rr * F + cc];
+                if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
+            }
+        if (q == 0) {
+            bvec[W * 16 + i] = b0;
+            bvec[WA::R1 * 16 + i] = b1;
+        }
+    } else {
+        // upper tiles only, tile-major: slot[tile][row][col]
+#pragma unroll
+        for (int j = 0; j < WA::N0; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[(C::row_start(W) + j) * 256 + (q * 4 + e) * 16 + i] = A.a0[j][e];
+#pragma unroll
+        for (int j = 0; j < WA::N1; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[(C::row_start(WA::R1) + j) * 256 + (q * 4 + e) * 16 + i] = A.a1[j][e];
+        if (q == 0) {
+            P[C::NTILES * 256 + W * 16 + i] = b0;
+            P[C::NTILES * 256 + WA::R1 * 16 + i] = b1;
+        }
+    }
+}
+
+// Chunk c of a row with n entries split into nch chunks starts at c * chunk_len(n, nch).
+__device__ __forceinline__ int64_t chunk_len(int64_t n, int nch) {
+    const int64_t per = (n + nch - 1) / nch;
+    return (per + TR - 1) / TR * TR;
+}
 
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G,
     const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ mslot_ptr,
-    const int32_t* __restrict__ chunk_row, int32_t chunk_nnz, int cg_steps, float* partials) {
-    constexpr int F = 32 * NT;
-    constexpr int NTHR = 64 * NT;
-    using L = SweepLds<NT>;
+    const int32_t* __restrict__ chunk_row, int cg_steps, float* partials) {
+    using C = GramCfg<NT>;
+    constexpr int F = C::F;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* big = smem;                                           // A (F x F) / two gather tiles
-    float2* wts = reinterpret_cast<float2*>(smem + L::BIGN);     // [2][TR] (|c|-1, max(c,0))
-    float* bvec = smem + L::BIGN + 2 * 2 * TR;                   // [F]
-    float* vec = bvec + F;                                       // [F] CG broadcast vector
+    float* big = smem;
+    float* bvec = smem + C::BIGN + 2 * TR * 2;
+    float* vec = bvec + F;
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int h = lane >> 5;
-    const int c = lane & 31;
 
     const int chunk = blockIdx.x;
     const int r = chunk_row[chunk];
@@ -309,98 +459,78 @@ __global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
     const int64_t rs = indptr[row], re = indptr[row + 1];
     float* xrow = X + row * F;
     if (rs == re) {
-        for (int i = tid; i < F; i += NTHR) xrow[i] = 0.f;
+        for (int i = tid; i < F; i += C::NTHR) xrow[i] = 0.f;
         return;
     }
-    const int64_t ks = rs + (int64_t)lc * chunk_nnz;
-    const int64_t ke = (ks + chunk_nnz < re) ? ks + chunk_nnz : re;
-    const int ntiles = (int)((ke - ks + TR - 1) / TR);
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    float bacc = 0.f;
-
-    Staged st;
-    load_tile<NT>(st, indices, data, Y, ks, ke, tid);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        float* tl = big + (tile & 1) * (TR * F);
-        float2* wt = wts + (tile & 1) * TR;
-        store_tile<NT>(st, tl, wt, tid);
-        __syncthreads();
-        if (tile + 1 < ntiles) load_tile<NT>(st, indices, data, Y, ks + (int64_t)(tile + 1) * TR, ke, tid);
-#pragma unroll 4
-        for (int s = 0; s < TR / 2; ++s) {
-            const int k = 2 * s + h;
-            const float2 wc = wt[k];
-            const float a_raw = tl[k * F + w * 32 + c];
-            float b[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = tl[k * F + t * 32 + c];
-            const float a = a_raw * wc.x;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
-            bacc = fmaf(wc.y, a_raw, bacc);
-        }
+    const int64_t clen = chunk_len(re - rs, nch);
+    const int64_t ks = rs + (int64_t)lc * clen;
+    const int64_t ke = (ks + clen < re) ? ks + clen : re;
+    const bool single = nch == 1;
+    float* P = single ? nullptr : partials + (size_t)(mslot_ptr[r] + lc) * C::PART_STRIDE;
+    if (ks >= ke) {
+        // rounding the chunk length up can leave a trailing chunk empty: its slot must still read as zero
+        for (int i = tid; i < C::PART_STRIDE; i += C::NTHR) P[i] = 0.f;
+        return;
     }
-    const float bsum = bacc + __shfl_xor(bacc, 32, 64);
-    __syncthreads();  // every wave is done with the gather tiles that alias `big`
 
-    if (nch == 1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = w * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const int cc = t * 32 + c;
-                big[rr * F + cc] = acc[t][i] + G[rr * F + cc];
-            }
-        if (h == 0) bvec[w * 32 + c] = bsum;
+    switch (w) {
+        case 0: gram_chunk_wave<NT, 0>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 1: if constexpr (NT > 1) gram_chunk_wave<NT, 1>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 2: if constexpr (NT > 2) gram_chunk_wave<NT, 2>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 3: if constexpr (NT > 3) gram_chunk_wave<NT, 3>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 4: if constexpr (NT > 4) gram_chunk_wave<NT, 4>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 5: if constexpr (NT > 5) gram_chunk_wave<NT, 5>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+    }
+    if (single) {
         __syncthreads();
         if (w == 0) cg_solve_wave<F>(big, bvec, vec, xrow, cg_steps, lane);
-    } else {
-        float* P = partials + (size_t)(mslot_ptr[r] + lc) * (F * F + F);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = w * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                P[rr * F + t * 32 + c] = acc[t][i];
-            }
-        if (h == 0) P[F * F + w * 32 + c] = bsum;
     }
 }
 
-// Split rows: sum the chunk partials in chunk order, add G, solve.
+// Split rows: sum the chunk partials in chunk order, add G, mirror the upper triangle, solve.
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
     int64_t row_begin, float* X, const float* __restrict__ G, const int32_t* __restrict__ chunk_ptr,
     const int32_t* __restrict__ mslot_ptr, const int32_t* __restrict__ multi_row, int cg_steps,
     const float* __restrict__ partials) {
-    constexpr int F = 32 * NT;
-    constexpr int NTHR = 64 * NT;
-    using L = SweepLds<NT>;
+    using C = GramCfg<NT>;
+    constexpr int F = C::F;
+    constexpr int NB = C::NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* big = smem;
-    float* bvec = smem + L::BIGN + 2 * 2 * TR;
+    float* bvec = smem + C::BIGN + 2 * TR * 2;
     float* vec = bvec + F;
 
     const int tid = threadIdx.x;
     const int r = multi_row[blockIdx.x];
     const int nch = chunk_ptr[r + 1] - chunk_ptr[r];
-    const float* P = partials + (size_t)mslot_ptr[r] * (F * F + F);
-    constexpr int STRIDE = F * F + F;
-    for (int e = tid; e < F * F; e += NTHR) {
+    const float* P = partials + (size_t)mslot_ptr[r] * C::PART_STRIDE;
+    for (int e = tid; e < C::PART_STRIDE; e += C::NTHR) {
         float s = 0.f;
-        for (int ch = 0; ch < nch; ++ch) s += P[(size_t)ch * STRIDE + e];
-        big[e] = s + G[e];
-    }
-    for (int e = tid; e < F; e += NTHR) {
-        float s = 0.f;
-        for (int ch = 0; ch < nch; ++ch) s += P[(size_t)ch * STRIDE + F * F + e];
-        bvec[e] = s;
+        int ch = 0;
+        for (; ch + 4 <= nch; ch += 4) {
+            const float p0 = P[(size_t)(ch + 0) * C::PART_STRIDE + e];
+            const float p1 = P[(size_t)(ch + 1) * C::PART_STRIDE + e];
+            const float p2 = P[(size_t)(ch + 2) * C::PART_STRIDE + e];
+            const float p3 = P[(size_t)(ch + 3) * C::PART_STRIDE + e];
+            s = ((s + p0) + p1) + p2;
+            s += p3;
+        }
+        for (; ch < nch; ++ch) s += P[(size_t)ch * C::PART_STRIDE + e];
+        if (e >= C::NTILES * 256) {
+            bvec[e - C::NTILES * 256] = s;
+        } else {
+            const int t = e >> 8, rr16 = (e >> 4) & 15, cc16 = e & 15;
+            int bi = 0, t0 = 0;  // band-row of tile t
+            while (t0 + (NB - bi) <= t) {
+                t0 += NB - bi;
+                ++bi;
+            }
+            const int bj = bi + (t - t0);
+            const int rr = bi * 16 + rr16, cc = bj * 16 + cc16;
+            big[rr * F + cc] = s + G[rr * F + cc];
+            if (bj > bi) big[cc * F + rr] = s + G[cc * F + rr];
+        }
     }
     __syncthreads();
     if (tid < 64) cg_solve_wave<F>(big, bvec, vec, X + (row_begin + r) * F, cg_steps, tid);
@@ -411,7 +541,7 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
                         float* X, const float* Y, const float* G, int cg_steps, const char* plan,
                         const PlanLayout& L, int32_t chunk_nnz, const int64_t counts[3], float* partials,
                         hipStream_t stream) {
-    using S = SweepLds<NT>;
+    using S = GramCfg<NT>;
     const int32_t* chunk_ptr = (const int32_t*)(plan + L.chunk_ptr);
     const int32_t* mslot_ptr = (const int32_t*)(plan + L.mslot_ptr);
     const int32_t* chunk_row = (const int32_t*)(plan + L.chunk_row);
@@ -426,8 +556,7 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
     }
     if (counts[0] > 0) {
         hipLaunchKernelGGL(als_gram_cg_kernel<NT>, dim3((unsigned)counts[0]), dim3(64 * NT), S::BYTES, stream, indptr,
-                           indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row, chunk_nnz, cg_steps,
-                           partials);
+                           indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row, cg_steps, partials);
         MIREC_LAUNCH_CHECK();
     }
     if (counts[1] > 0) {
@@ -464,7 +593,7 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
     MIREC_REQUIRE(nrows < (int64_t)1 << 31, MIREC_E_UNSUPPORTED, "mirec_als_plan_build: more than 2^31 rows in one range");
     int32_t ch = *chunk_nnz;
     if (ch <= 0) ch = auto_chunk(nnz);
-    MIREC_REQUIRE(ch % TR == 0, MIREC_E_INVALID, "mirec_als_plan_build: chunk_nnz %d is not a multiple of %d", ch, TR);
+    MIREC_REQUIRE(ch > 0, MIREC_E_INVALID, "mirec_als_plan_build: chunk_nnz must be positive");
     const PlanLayout L = plan_layout(nrows, nnz, ch);
     MIREC_REQUIRE(plan_bytes >= L.total, MIREC_E_WORKSPACE, "mirec_als_plan_build: plan needs %zu bytes, %zu given",
                   L.total, plan_bytes);
@@ -508,7 +637,8 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
 extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], int f) {
     if (!host_counts || f <= 0) return 0;
     const size_t slots = host_counts[2] > 0 ? (size_t)host_counts[2] : 1;
-    return slots * ((size_t)f * f + f) * sizeof(float);
+    const size_t nb = (size_t)f / 16;  // upper-triangle 16x16 tiles + the b vector (GramCfg::PART_STRIDE)
+    return slots * (nb * (nb + 1) / 2 * 256 + f) * sizeof(float);
 }
 
 extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data,
@@ -522,8 +652,7 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     MIREC_REQUIRE(row_end >= row_begin && cg_steps >= 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad range or cg_steps");
     MIREC_REQUIRE(f % 32 == 0 && f >= 32 && f <= 192, MIREC_E_UNSUPPORTED,
                   "mirec_als_half_sweep: factor width %d is not a multiple of 32 in [32,192]; zero-pad the columns", f);
-    MIREC_REQUIRE(chunk_nnz > 0 && chunk_nnz % TR == 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad chunk_nnz %d",
-                  chunk_nnz);
+    MIREC_REQUIRE(chunk_nnz > 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad chunk_nnz %d", chunk_nnz);
     MIREC_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, MIREC_E_INVALID,
                   "mirec_als_half_sweep: factor matrices must be 16-byte aligned");
     MIREC_REQUIRE(host_counts[2] == 0 || (ws && ws_bytes >= mirec_als_sweep_workspace_bytes(host_counts, f)),

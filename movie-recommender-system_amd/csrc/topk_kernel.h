@@ -1,18 +1,26 @@
 // Fused score + top-K: scores = Q . Y^T on the fp32 matrix cores, selection in
 // LDS, nothing but the k winners per query ever reaches memory.
 //
-// A workgroup owns 32*WAVES query rows and sweeps all items in tiles of
-// BI = 32*NTI rows of Y staged in LDS.  Each wavefront keeps its 32 queries as
-// MFMA A operands in registers and produces a 32 x BI score tile per item tile
-// with v_mfma_f32_32x32x2_f32, which evaluates, per (query, item), exactly the
-// chain s = fma(q[k], y[k], s) for ascending k.  Every wavefront owns the
-// selection state of its 32 queries (no cross-wave traffic): a buffer of CAP
-// (score, item) entries per query, of which the first k after a compaction are
-// the current best, and a threshold tau = score of the k-th best.  A score
-// enters the buffer only if it beats tau; a full buffer is compacted by a
-// wave-wide rank sort under the order (score desc, item asc).  Items arrive in
-// ascending index order, so a later item that ties the k-th best never
-// displaces it and `score > tau` is exact.
+// A workgroup owns 32*WAVES query rows and sweeps all items in tiles of 32
+// rows of Y staged in LDS.  Each wavefront keeps its 32 queries as MFMA A
+// operands in registers and produces a 32 x 32 score tile per item tile with
+// v_mfma_f32_32x32x2_f32, which evaluates, per (query, item), exactly the chain
+// s = fma(q[k], y[k], s) for ascending k.
+//
+// Selection state is private to a wavefront (no cross-wave traffic): per query
+// a buffer of CAP (score, item) entries, of which the first k after a
+// compaction are the current best, and a threshold tau = score of the k-th
+// best, mirrored in registers.  A score enters the buffer only if it beats tau
+// (one LDS atomic for the slot); before every tile each query's buffer has at
+// least 32 free slots, so a tile can never overflow it; buffers past that mark
+// are compacted by a wave-wide rank sort under the order (score desc, item
+// asc).  Items arrive in ascending index order, so a later item that ties the
+// k-th best never displaces it and `score > tau` is exact.  Liked items are
+// found by a per-query cursor over the (ascending) mask row and turned into
+// -FLT_MAX only when they come up as candidates.
+//
+// Two workgroups share a CU at the usual widths, so one wavefront's selection
+// and staging overlap the other's MFMA phase.
 #pragma once
 #include <float.h>
 #include <math.h>
@@ -28,7 +36,7 @@ __device__ __forceinline__ bool better(float sa, int ia, float sb, int ib) {
 // Keep the best min(n, k) entries of one query's buffer, sorted, at the front.
 template <int CAP>
 __device__ __forceinline__ void compact_wave(float* ss, int* ii, int* cntp, float* taup, int k, int lane) {
-    constexpr int E = CAP / 64;
+    constexpr int E = (CAP + 63) / 64;
     const int n = __builtin_amdgcn_readfirstlane(*cntp);
     float ms[E];
     int mi[E];
@@ -65,29 +73,31 @@ __device__ __forceinline__ void compact_wave(float* ss, int* ii, int* cntp, floa
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int F, int WAVES, int NTI, int CAP>
+constexpr int TOPK_BI = 32;  // item rows per tile
+
+template <int F, int WAVES, int CAP>
 struct TopkLds {
-    static constexpr int BI = 32 * NTI;
     static constexpr int LDY = F + 1;  // odd stride: column reads of a tile hit 32 distinct banks
-    static constexpr int YT = BI * LDY;
-    static constexpr int PER_WAVE = 32 * CAP * 2 + 64;  // scores, ids, counts, thresholds
+    static constexpr int YT = TOPK_BI * LDY;
+    static constexpr int PER_WAVE = 32 * CAP * 2 + 32 * 3;  // scores, ids, counts, thresholds, liked bits
     static constexpr size_t BYTES = (size_t)(YT + WAVES * PER_WAVE) * 4;
 };
 
-template <int F, int WAVES, int NTI, int CAP>
+template <int F, int WAVES, int CAP>
 __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     const float* __restrict__ Q, int64_t nq, const float* __restrict__ Y, int64_t ni,
     const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices,
     const float* __restrict__ y_norm, const float* __restrict__ q_norm, int k, int32_t* __restrict__ out_ids,
     float* __restrict__ out_scores) {
-    using L = TopkLds<F, WAVES, NTI, CAP>;
+    using L = TopkLds<F, WAVES, CAP>;
     constexpr int KS = F / 2;
-    constexpr int BI = L::BI;
+    constexpr int BI = TOPK_BI;
     constexpr int LDY = L::LDY;
     constexpr int NTHR = 64 * WAVES;
     constexpr int TILE_V4 = BI * F / 4;
     constexpr int NV = (TILE_V4 + NTHR - 1) / NTHR;
     constexpr int F4 = F / 4;
+    constexpr int FULL = CAP - 32;  // compact a buffer once it holds more than this
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ytile = smem;
@@ -100,11 +110,13 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     int* sel_i = reinterpret_cast<int*>(sel_s + 32 * CAP);
     int* cnt = sel_i + 32 * CAP;
     float* tau = reinterpret_cast<float*>(cnt + 32);
+    unsigned* lmask = reinterpret_cast<unsigned*>(tau + 32);  // [32]: liked bits of the current item tile
 
     const int64_t u0 = (int64_t)blockIdx.x * (32 * WAVES) + w * 32;  // first query of this wave
     if (lane < 32) {
         cnt[lane] = 0;
         tau[lane] = -INFINITY;
+        lmask[lane] = 0u;
     }
 
     // A operands: query row u0 + c, elements k = 2s + h
@@ -118,6 +130,28 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
             const float v = qr[2 * s];
             qa[s] = uv ? v : 0.f;
         }
+    }
+
+    // Score acc[i] of this lane belongs to query row (i&3) + 8*(i>>2) + 4h; its threshold and divisor:
+    float tau_r[16];
+    float qn_r[16];
+    bool urow_ok[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t ug = u0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        tau_r[i] = -INFINITY;
+        urow_ok[i] = ug < nq;
+        qn_r[i] = (q_norm != nullptr && ug < nq) ? q_norm[ug] : 1.f;
+    }
+
+    // Liked-item filter: lane u < 32 walks the (ascending) mask row of query u0 + u with a cursor, one
+    // entry prefetched, and turns the entries that fall into the current item tile into a bit mask.
+    int64_t cur = 0, cend = 0;
+    int nxt = 0x7fffffff;
+    if (mask_indptr != nullptr && lane < 32 && u0 + lane < nq) {
+        cur = mask_indptr[u0 + lane];
+        cend = mask_indptr[u0 + lane + 1];
+        if (cur < cend) nxt = mask_indices[cur];
     }
 
     float4 pre[NV];
@@ -157,73 +191,98 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
         __syncthreads();
         if (i0 + BI < ni) load_y(i0 + BI);
 
-        f32x16 acc[NTI];
+        f32x16 acc;
 #pragma unroll
-        for (int t = 0; t < NTI; ++t)
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        // B operands are fetched one batch of k-steps ahead of the MFMAs that consume them; the scheduling
+        // barriers keep the compiler from sinking each read next to its use (which would stall every MFMA
+        // pair on an LDS round trip).
+        {
+            constexpr int KB = 8;                  // k-steps per batch
+            constexpr int NB = (KS + KB - 1) / KB;
+            const float* yrow = ytile + c * LDY + h;
+            float bq[2][KB];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+            for (int j = 0; j < KB; ++j) bq[0][j] = (j < KS) ? yrow[2 * j] : 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+            for (int bt = 0; bt < NB; ++bt) {
+                if (bt + 1 < NB) {
 #pragma unroll
-            for (int t = 0; t < NTI; ++t) {
-                const float b = ytile[(t * 32 + c) * LDY + 2 * s + h];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], b, acc[t], 0, 0, 0);
+                    for (int j = 0; j < KB; ++j) {
+                        const int s = (bt + 1) * KB + j;
+                        bq[(bt + 1) & 1][j] = (s < KS) ? yrow[2 * s] : 0.f;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const int s = bt * KB + j;
+                    if (s < KS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], bq[bt & 1][j], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
-        // ---- selection: acc[t][i] = score(query u0 + row(i,h), item i0 + 32t + c)
+        if (mask_indptr != nullptr) {
+            if (lane < 32) {
+                unsigned mw = 0u;
+                const int64_t lim = i0 + BI;
+                while ((int64_t)nxt < lim) {
+                    const int bit = nxt - (int)i0;
+                    if (bit >= 0) mw |= 1u << bit;
+                    ++cur;
+                    nxt = cur < cend ? mask_indices[cur] : 0x7fffffff;
+                }
+                lmask[lane] = mw;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- selection: acc[i] = score(query u0 + row(i,h), item i0 + c)
+        const int64_t item = i0 + c;
+        const bool item_ok = item < ni;
+        float yn = 1.f;
+        if (y_norm != nullptr) yn = y_norm[item_ok ? item : 0];
+        unsigned pm = 0u;
+        float sc[16];
 #pragma unroll
-        for (int t = 0; t < NTI; ++t) {
-            const int64_t item = i0 + t * 32 + c;
-            const bool item_ok = item < ni;
-            float yn = 1.f;
-            if (y_norm != nullptr) yn = y_norm[item_ok ? item : 0];
+        for (int i = 0; i < 16; ++i) {
+            float s = acc[i];
+            if (y_norm != nullptr) s = s / yn;
+            if (q_norm != nullptr) s = s / qn_r[i];
+            sc[i] = s;
+            pm |= (item_ok && urow_ok[i] && s > tau_r[i]) ? (1u << i) : 0u;
+        }
+        if (__ballot(pm != 0u) != 0ull) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int rbase = (i & 3) + 8 * (i >> 2);
-                const int ur = rbase + 4 * h;
-                const int64_t ug = u0 + ur;
-                float s = acc[t][i];
-                if (y_norm != nullptr) s = s / yn;
-                if (q_norm != nullptr) s = s / q_norm[ug < nq ? ug : 0];
-                bool pass = item_ok && ug < nq && s > tau[ur];
-                if (__ballot(pass) == 0ull) continue;
-                if (pass && mask_indptr != nullptr) {
-                    int64_t lo = mask_indptr[ug], hi = mask_indptr[ug + 1];
-                    while (lo < hi) {
-                        const int64_t mid = (lo + hi) >> 1;
-                        if (mask_indices[mid] < (int32_t)item) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo < mask_indptr[ug + 1] && mask_indices[lo] == (int32_t)item) {
+                if ((pm >> i) & 1u) {
+                    const int ur = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    float s = sc[i];
+                    bool push = true;
+                    if (mask_indptr != nullptr && ((lmask[ur] >> c) & 1u)) {
                         s = -FLT_MAX;
-                        pass = s > tau[ur];
+                        push = s > tau_r[i];
+                    }
+                    if (push) {
+                        const int pos = atomicAdd(&cnt[ur], 1);
+                        sel_s[ur * CAP + pos] = s;
+                        sel_i[ur * CAP + pos] = (int)item;
                     }
                 }
-                unsigned long long bal = __ballot(pass);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // restore the invariant "at least 32 free slots per query"
+            const bool need = lane < 32 && cnt[lane] > FULL;
+            unsigned long long bal = __ballot(need);
+            if (bal != 0ull) {
+                while (bal != 0ull) {
+                    const int u = __builtin_ctzll(bal);
+                    bal &= bal - 1ull;
+                    compact_wave<CAP>(sel_s + u * CAP, sel_i + u * CAP, cnt + u, tau + u, k, lane);
+                }
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    unsigned m = (unsigned)(bal >> (32 * half));
-                    if (m == 0u) continue;
-                    const int urh = rbase + 4 * half;
-                    int base = __builtin_amdgcn_readfirstlane(cnt[urh]);
-                    int n = __popc(m);
-                    if (base + n > CAP) {
-                        compact_wave<CAP>(sel_s + urh * CAP, sel_i + urh * CAP, cnt + urh, tau + urh, k, lane);
-                        if (h == half) pass = pass && s > tau[urh];
-                        bal = __ballot(pass);
-                        m = (unsigned)(bal >> (32 * half));
-                        n = __popc(m);
-                        base = __builtin_amdgcn_readfirstlane(cnt[urh]);
-                    }
-                    if (h == half && pass) {
-                        const int pos = base + __popc(m & ((1u << c) - 1u));
-                        sel_s[urh * CAP + pos] = s;
-                        sel_i[urh * CAP + pos] = (int)item;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) cnt[urh] = base + n;
-                    __builtin_amdgcn_wave_barrier();
-                }
+                for (int i = 0; i < 16; ++i) tau_r[i] = tau[(i & 3) + 8 * (i >> 2) + 4 * h];
             }
         }
     }
@@ -241,34 +300,37 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     }
 }
 
-template <int F, int WAVES, int NTI, int CAP>
+template <int F, int WAVES, int CAP>
 static int launch_topk_cfg(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
                            const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k,
                            int32_t* out_ids, float* out_scores, hipStream_t stream) {
-    using L = TopkLds<F, WAVES, NTI, CAP>;
+    using L = TopkLds<F, WAVES, CAP>;
     static bool attr_done = false;  // idempotent; a race only repeats the call
     if (!attr_done) {
-        MIREC_HIP(hipFuncSetAttribute((const void*)topk_kernel<F, WAVES, NTI, CAP>,
+        MIREC_HIP(hipFuncSetAttribute((const void*)topk_kernel<F, WAVES, CAP>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
         attr_done = true;
     }
     const int64_t blocks = (nq + 32 * WAVES - 1) / (32 * WAVES);
-    hipLaunchKernelGGL((topk_kernel<F, WAVES, NTI, CAP>), dim3((unsigned)blocks), dim3(64 * WAVES), L::BYTES, stream,
-                       Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids, out_scores);
+    hipLaunchKernelGGL((topk_kernel<F, WAVES, CAP>), dim3((unsigned)blocks), dim3(64 * WAVES), L::BYTES, stream, Q, nq,
+                       Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids, out_scores);
     MIREC_LAUNCH_CHECK();
     return MIREC_OK;
 }
 
+// Buffer size by k: CAP - 32 >= k.  56 entries (k <= 24) lets two 4-wave workgroups share a CU.
 template <int F>
 int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
-                       const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k,
-                       int32_t* out_ids, float* out_scores, hipStream_t stream) {
-    if (k <= 32)
-        return launch_topk_cfg<F, 4, 2, 64>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
-                                            out_scores, stream);
-    return launch_topk_cfg<F, 2, 1, 256>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
+                const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
+                float* out_scores, hipStream_t stream) {
+    if (k <= 24)
+        return launch_topk_cfg<F, 4, 56>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
                                          out_scores, stream);
+    if (k <= 96)
+        return launch_topk_cfg<F, 4, 128>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
+                                          out_scores, stream);
+    return launch_topk_cfg<F, 2, 256>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
+                                      out_scores, stream);
 }
 
 }  // namespace mirec
-
