@@ -11,10 +11,10 @@
 // a buffer of CAP (score, item) entries, of which the first k after a
 // compaction are the current best, and a threshold tau = score of the k-th
 // best, mirrored in registers.  A score enters the buffer only if it beats tau
-// (one LDS atomic for the slot); before every tile each query's buffer has at
-// least 32 free slots, so a tile can never overflow it; buffers past that mark
+// (one LDS atomic reserves the slot); when a reservation fails the full buffers
 // are compacted by a wave-wide rank sort under the order (score desc, item
-// asc).  Items arrive in ascending index order, so a later item that ties the
+// asc), which also raises tau, and the push is retried (CAP >= k + 32, so all
+// 32 lanes of a tile row fit after a compaction).  Items arrive in ascending index order, so a later item that ties the
 // k-th best never displaces it and `score > tau` is exact.  Liked items are
 // found by a per-query cursor over the (ascending) mask row and turned into
 // -FLT_MAX only when they come up as candidates.
@@ -37,7 +37,8 @@ __device__ __forceinline__ bool better(float sa, int ia, float sb, int ib) {
 template <int CAP>
 __device__ __forceinline__ void compact_wave(float* ss, int* ii, int* cntp, float* taup, int k, int lane) {
     constexpr int E = (CAP + 63) / 64;
-    const int n = __builtin_amdgcn_readfirstlane(*cntp);
+    int n = __builtin_amdgcn_readfirstlane(*cntp);
+    n = n < CAP ? n : CAP;  // failed reservations may have pushed the counter past the capacity
     float ms[E];
     int mi[E];
     int rank[E];
@@ -97,7 +98,6 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     constexpr int TILE_V4 = BI * F / 4;
     constexpr int NV = (TILE_V4 + NTHR - 1) / NTHR;
     constexpr int F4 = F / 4;
-    constexpr int FULL = CAP - 32;  // compact a buffer once it holds more than this
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ytile = smem;
@@ -154,8 +154,10 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
         if (cur < cend) nxt = mask_indices[cur];
     }
 
-    float4 pre[NV];
-    auto load_y = [&](int64_t i0) {
+    // Item tiles are fetched two tiles ahead into registers (pre0 / pre1 alternate), so that an L2 or
+    // Infinity-Cache round trip is covered by two tiles of MFMA work even at small widths.
+    f32x4 pre0[NV], pre1[NV];
+    auto load_y = [&](f32x4 (&pre)[NV], int64_t i0) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int e = tid + v * NTHR;
@@ -163,12 +165,12 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
             const int k4 = e % F4;
             const int64_t item = i0 + j;
             if (e < TILE_V4 && item < ni)
-                pre[v] = *reinterpret_cast<const float4*>(Y + item * F + 4 * k4);
+                pre[v] = *reinterpret_cast<const f32x4*>(Y + item * F + 4 * k4);
             else
-                pre[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                pre[v] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto store_y = [&]() {
+    auto store_y = [&](const f32x4 (&pre)[NV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int e = tid + v * NTHR;
@@ -176,21 +178,16 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
                 const int j = e / F4;
                 const int k4 = e % F4;
                 float* d = ytile + j * LDY + 4 * k4;
-                d[0] = pre[v].x;
-                d[1] = pre[v].y;
-                d[2] = pre[v].z;
-                d[3] = pre[v].w;
+                d[0] = pre[v][0];
+                d[1] = pre[v][1];
+                d[2] = pre[v][2];
+                d[3] = pre[v][3];
             }
         }
     };
 
-    load_y(0);
-    for (int64_t i0 = 0; i0 < ni; i0 += BI) {
-        __syncthreads();  // previous tile fully consumed
-        store_y();
-        __syncthreads();
-        if (i0 + BI < ni) load_y(i0 + BI);
-
+    // MFMA + selection of the tile that sits in LDS
+    auto process_tile = [&](int64_t i0) __attribute__((always_inline)) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -245,37 +242,47 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
         if (y_norm != nullptr) yn = y_norm[item_ok ? item : 0];
         unsigned pm = 0u;
         float sc[16];
+        if (y_norm != nullptr || q_norm != nullptr) {
+            // similar-items mode only; the empty asm keeps this a real (wave-uniform) branch: if-converted,
+            // the 32 IEEE divisions would run on every tile of every plain scoring pass
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float s = acc[i];
-            if (y_norm != nullptr) s = s / yn;
-            if (q_norm != nullptr) s = s / qn_r[i];
-            sc[i] = s;
-            pm |= (item_ok && urow_ok[i] && s > tau_r[i]) ? (1u << i) : 0u;
+            for (int i = 0; i < 16; ++i) sc[i] = (acc[i] / yn) / qn_r[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = acc[i];
         }
-        if (__ballot(pm != 0u) != 0ull) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if ((pm >> i) & 1u) {
-                    const int ur = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    float s = sc[i];
-                    bool push = true;
-                    if (mask_indptr != nullptr && ((lmask[ur] >> c) & 1u)) {
-                        s = -FLT_MAX;
-                        push = s > tau_r[i];
-                    }
-                    if (push) {
-                        const int pos = atomicAdd(&cnt[ur], 1);
+        for (int i = 0; i < 16; ++i) pm |= (item_ok && urow_ok[i] && sc[i] > tau_r[i]) ? (1u << i) : 0u;
+        // Candidates: a lane rarely holds more than one per tile, so they are taken one at a time (lowest
+        // row first) with a select chain.  A slot is reserved with one LDS atomic; when the buffer is full
+        // the push fails, the full buffers are compacted (which also raises tau) and the lane retries.
+        while (__ballot(pm != 0u) != 0ull) {
+            bool failed = false;
+            if (pm != 0u) {
+                const int i = __builtin_ctz(pm);
+                float s = sc[0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) {
+                    s = (i == j) ? sc[j] : s;
+                    asm volatile("" : "+v"(s));  // keep it a select chain (not a spilled table lookup)
+                }
+                const int ur = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (mask_indptr != nullptr && ((lmask[ur] >> c) & 1u)) s = -FLT_MAX;
+                if (s > tau[ur]) {
+                    const int pos = atomicAdd(&cnt[ur], 1);
+                    if (pos < CAP) {
                         sel_s[ur * CAP + pos] = s;
                         sel_i[ur * CAP + pos] = (int)item;
+                    } else {
+                        failed = true;
                     }
                 }
+                if (!failed) pm &= pm - 1u;
             }
-            __builtin_amdgcn_wave_barrier();
-            // restore the invariant "at least 32 free slots per query"
-            const bool need = lane < 32 && cnt[lane] > FULL;
-            unsigned long long bal = __ballot(need);
-            if (bal != 0ull) {
+            if (__ballot(failed) != 0ull) {
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long bal = __ballot(lane < 32 && cnt[lane] >= CAP);
                 while (bal != 0ull) {
                     const int u = __builtin_ctzll(bal);
                     bal &= bal - 1ull;
@@ -285,6 +292,22 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
                 for (int i = 0; i < 16; ++i) tau_r[i] = tau[(i & 3) + 8 * (i >> 2) + 4 * h];
             }
         }
+    };
+
+    load_y(pre0, 0);
+    load_y(pre1, BI);
+    for (int64_t i0 = 0; i0 < ni; i0 += 2 * BI) {
+        __syncthreads();  // previous tile fully consumed
+        store_y(pre0);
+        __syncthreads();
+        load_y(pre0, i0 + 2 * BI);
+        process_tile(i0);
+        if (i0 + BI >= ni) break;
+        __syncthreads();
+        store_y(pre1);
+        __syncthreads();
+        load_y(pre1, i0 + 3 * BI);
+        process_tile(i0 + BI);
     }
 
     // ---- final compaction and output
