@@ -220,7 +220,7 @@ def main():
         flops = 2.0 * (u1 - u0) * I * W
         extra["top20_users_per_s"] = U / tk
         extra["top20_pass_ms"] = tk * 1e3
-        extra["topk_roofline"] = {"kernel": f"topk_kernel<{W},4,2,64>", "bound": "mfma",
+        extra["topk_roofline"] = {"kernel": "topk_kernel<%d,%s>" % (W, "4,56" if args.topk <= 24 else "4,128" if args.topk <= 96 else "2,256"), "bound": "mfma",
                                   "achieved": flops / tk / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": flops / tk / 1e12 / MFMA_F32_PEAK_TFLOPS}
         del ids, scores

@@ -20,7 +20,7 @@ SOURCES = ["core.hip", "gram.hip", "als_sweep.hip", "als_short.hip", "topk.hip",
            "topk_inst_2.hip", "topk_inst_3.hip", "topk_inst_4.hip", "topk_inst_5.hip", "lightfm.hip", "transpose.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "topk_kernel.h"), os.path.join(ROOT, "include", "mirec.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("MIREC_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:

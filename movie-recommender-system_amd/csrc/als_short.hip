@@ -9,23 +9,35 @@
 // Cache, as the item factors do in the user half-sweep; rows beyond
 // `short_max` go to the explicit-Gram kernel in als_sweep.hip.
 //
-// Layout: persistent workgroups of 8 wavefronts; G (F x F) sits in LDS, shared
-// by all of them; the rest of the LDS is split into one cache per wavefront
-// that keeps the first CAP gathered rows of the current CSR row, so short rows
-// are fetched once and re-read on chip.  Within a wavefront the two 32-lane
-// halves take alternate gathered rows (16-byte loads at F = 128: lane c owns
-// columns [c*NT, c*NT+NT)), 16 rows each per step; their 16 dot products are
-// reduced across the 32 lanes by one reduce-scatter butterfly (2 shuffles per
-// row instead of 5), after which lane pair (2j, 2j+1) holds row j's dot.
+// Layout: persistent workgroups of 16 wavefronts (8 beyond F = 128); G (F x F)
+// sits in LDS, shared by all of them; the rest of the LDS is split into one
+// cache per wavefront that keeps the first CAP gathered rows of the current
+// CSR row, so short rows are fetched once and re-read on chip.  Within a
+// wavefront the two 32-lane halves take alternate gathered rows (16-byte
+// loads at F = 128: lane c owns columns [c*NT, c*NT+NT)), GV rows each per
+// step; their GV dot products are reduced across the 32 lanes by one
+// reduce-scatter butterfly (about 2 shuffles per row instead of 5), after
+// which a group of 32/GV adjacent lanes holds row j's dot.
 #include "als_internal.h"
 
 namespace mirec {
 
-constexpr int SW = 8;   // wavefronts per workgroup
-constexpr int GV = 16;  // gathered rows per half-wave per step
+// Wavefronts per workgroup and gathered rows per half-wave per step.  The kernel is bound by latency and by
+// LDS instruction issue, not by registers well spent: measured on the 1 M x 27 k user half-sweep at F = 128,
+// (waves, rows/step) = (8,16) 12.8 ms, (8,8) 14.3, (12,8) 10.7, (16,8) 10.5 -- so up to F = 128 the kernel runs
+// 16 waves (4 per SIMD, 128 VGPRs) with 8 rows per step; wider rows keep 8 waves and 16 rows per step.
+#ifndef MIREC_SHORT_GV
+#define MIREC_SHORT_GV 8
+#endif
+constexpr int GV = MIREC_SHORT_GV;  // gathered rows per half-wave per step (8 or 16)
+template <int NT>
+struct ShortWaves {
+    static constexpr int SW = NT <= 4 ? 16 : 8;
+};
 
 template <int NT>
 struct ShortLds {
+    static constexpr int SW = ShortWaves<NT>::SW;
     static constexpr int F = 32 * NT;
     static constexpr int TOTAL = 160 * 1024 / 4;                       // floats of LDS per CU
     static constexpr int AVAIL = TOTAL - F * F - SW * F - 64;
@@ -82,9 +94,10 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
-// 16 values per lane -> lane pair (2j, 2j+1) of each half holds the 32-lane sum of value j.
-__device__ __forceinline__ float reduce_scatter16(float (&p)[GV], int c) {
-    {
+// GV values per lane -> after the butterfly, lane c of each half holds the 32-lane sum of value
+// (c >> 1) & 15 (GV = 16) or (c >> 2) & 7 (GV = 8).
+__device__ __forceinline__ float reduce_scatter(float (&p)[GV], int c) {
+    if constexpr (GV == 16) {
         const bool up = (c & 16) != 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -93,32 +106,38 @@ __device__ __forceinline__ float reduce_scatter16(float (&p)[GV], int c) {
             p[i] = keep + __shfl_xor(send, 16, 64);
         }
     }
+    constexpr int S1 = GV == 16 ? 8 : 16;  // lane bit that halves 8 values to 4
     {
-        const bool up = (c & 8) != 0;
+        const bool up = (c & S1) != 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float keep = up ? p[i + 4] : p[i];
             const float send = up ? p[i] : p[i + 4];
-            p[i] = keep + __shfl_xor(send, 8, 64);
+            p[i] = keep + __shfl_xor(send, S1, 64);
         }
     }
     {
-        const bool up = (c & 4) != 0;
+        const bool up = (c & (S1 >> 1)) != 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float keep = up ? p[i + 2] : p[i];
             const float send = up ? p[i] : p[i + 2];
-            p[i] = keep + __shfl_xor(send, 4, 64);
+            p[i] = keep + __shfl_xor(send, S1 >> 1, 64);
         }
     }
     {
-        const bool up = (c & 2) != 0;
+        const bool up = (c & (S1 >> 2)) != 0;
         const float keep = up ? p[1] : p[0];
         const float send = up ? p[0] : p[1];
-        p[0] = keep + __shfl_xor(send, 2, 64);
+        p[0] = keep + __shfl_xor(send, S1 >> 2, 64);
     }
-    return p[0] + __shfl_xor(p[0], 1, 64);
+    float d = p[0];
+#pragma unroll
+    for (int off = S1 >> 3; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+    return d;
 }
+
+constexpr int DSH = GV == 16 ? 1 : 2;  // lane c holds the dot of gathered row (c >> DSH) of its half's step
 
 // acc (per half: the sum over that half's gathered rows) of
 //   FIRST:  (max(c,0) - (|c|-1)(y.v)) y        (start residual, v = x)
@@ -169,8 +188,8 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
             for (int t = 0; t < NT; ++t) s = fmaf(yv[j][t], v[t], s);
             part[j] = s;
         }
-        const float d = reduce_scatter16(part, c);
-        const int kkm = g0 + 2 * (c >> 1) + h;
+        const float d = reduce_scatter(part, c);
+        const int kkm = g0 + 2 * (c >> DSH) + h;
         float coef = 0.f;
         if (kkm < n) {
             const float cv = data[kkm];
@@ -179,7 +198,7 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
         }
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
-            const float cj = __shfl(coef, (h << 5) | (2 * j), 64);
+            const float cj = __shfl(coef, (h << 5) | (j << DSH), 64);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = fmaf(cj, yv[j][t], acc[t]);
         }
@@ -218,13 +237,14 @@ __device__ __forceinline__ void symv_short(const float* Gs, float* vec, const fl
 }
 
 template <int NT>
-__global__ __launch_bounds__(64 * SW) void als_short_kernel(
+__global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, int64_t nrows, float* X, const float* __restrict__ Y, const float* __restrict__ G,
     int32_t short_max, int cg_steps) {
     constexpr int F = 32 * NT;
     using L = ShortLds<NT>;
     constexpr int CAP = L::CAP;
+    constexpr int SW = L::SW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Gs = smem;
     const int tid = threadIdx.x;
@@ -302,6 +322,7 @@ static int launch_short(const int64_t* indptr, const int32_t* indices, const flo
                         int64_t nrows, float* X, const float* Y, const float* G, int32_t short_max, int cg_steps,
                         hipStream_t stream) {
     using L = ShortLds<NT>;
+    constexpr int SW = L::SW;
     static bool attr_done = false;  // idempotent; a race only repeats the call
     static int cus = 0;
     if (!attr_done) {
