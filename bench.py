@@ -21,6 +21,7 @@ roofline) and the per-kernel times.
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -179,13 +180,34 @@ def main():
             out.append(("als_gram_cg_kernel", None, t_m / c_m, c_m))
         return out
 
+    # HBM-side bytes per launch cannot be read from inside this process: they come from separate
+    # rocprofv3 --pmc passes over the same workload, whose summary is committed next to the kernel
+    # statistics.  They are attached only when workload and world size match that capture.
+    def pmc_traffic(tag, kernel):
+        if world != 1:
+            return None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+            try:
+                d = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            w = d.get("workload", {})
+            if (w.get("users"), w.get("items"), w.get("factors"), w.get("seed"), w.get("mean_degree")) != \
+                    (U, I, f, args.seed, args.mean_degree):
+                continue
+            e = d.get(tag, {}).get("mirec::" + kernel, {})
+            if "hbm_bytes_per_launch" in e:
+                return e["hbm_bytes_per_launch"]
+        return None
+
     entries = [(tag, k, b, ms, n) for tag, csr, plan in (("user", eng.Cui_local, eng.plan_u), ("item", eng.Ciu_local, eng.plan_i))
                for (k, b, ms, n) in side(tag, csr, plan)]
     rl_all = []
     for tag, k, b, ms, n in entries:
         gbs = (b / (ms * 1e-3) / 1e9) if (b and ms > 0) else None
         rl_all.append({"side": tag, "kernel": f"{k}<{F // 32}>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": None,
+                       "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None,
+                       "traffic": pmc_traffic(tag, f"{k}<{F // 32}>"),
                        "bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n})
     dom = max(rl_all, key=lambda e: e["avg_launch_ms"]) if rl_all else None
     roofline = dict(dom) if dom else None
