@@ -75,6 +75,7 @@ int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, 
  * rows spread over many workgroups.  The plan depends only on `indptr` and can
  * be reused for every iteration of a fit.
  *   nnz         stored entries in rows [row_begin, row_end)
+ *   y_rows      rows of Y; every stored index is below it (0 = not known)
  *   plan        device buffer of mirec_als_plan_bytes(nrows, nnz, chunk_nnz)
  *   chunk_nnz   in: rows with more stored entries than this are split (into at
  *               most 32 equal chunks); 0 = choose from nnz; out: the value used
@@ -93,7 +94,7 @@ int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_e
                          int64_t host_counts[4], mirec_stream_t stream);
 size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], int f);
 int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
-                         int64_t row_end, int64_t nnz, float* X, const float* Y, const float* G, int f,
+                         int64_t row_end, int64_t nnz, float* X, const float* Y, int64_t y_rows, const float* G, int f,
                          int cg_steps, const void* plan, int32_t chunk_nnz, int32_t short_max,
                          const int64_t host_counts[4], void* ws, size_t ws_bytes, mirec_stream_t stream);
 

@@ -5,8 +5,9 @@
 
 namespace mirec {
 
-// Matrix-free wave-per-row solver for rows with at most short_max entries (als_short.hip).
-int launch_als_short(int nt, const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
+// Matrix-free wave-per-row solver for rows with at most short_max entries (als_short.hip).  y_rows = rows of
+// the gathered table Y (<= 0: unknown, 64-bit addressing).
+int launch_als_short(int nt, int64_t y_rows, const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                      int64_t nrows, float* X, const float* Y, const float* G, int32_t short_max, int cg_steps,
                      hipStream_t stream);
 

@@ -22,14 +22,12 @@
 
 namespace mirec {
 
-// Wavefronts per workgroup and gathered rows per half-wave per step.  The kernel is bound by latency and by
-// LDS instruction issue, not by registers well spent: measured on the 1 M x 27 k user half-sweep at F = 128,
+// Wavefronts per workgroup and gathered rows per half-wave per step.  The kernel is bound by vector-instruction
+// issue and latency, not by registers well spent: measured on the 1 M x 27 k user half-sweep at F = 128,
 // (waves, rows/step) = (8,16) 12.8 ms, (8,8) 14.3, (12,8) 10.7, (16,8) 10.5 -- so up to F = 128 the kernel runs
-// 16 waves (4 per SIMD, 128 VGPRs) with 8 rows per step; wider rows keep 8 waves and 16 rows per step.
-#ifndef MIREC_SHORT_GV
-#define MIREC_SHORT_GV 8
-#endif
-constexpr int GV = MIREC_SHORT_GV;  // gathered rows per half-wave per step (8 or 16)
+// 16 waves (4 per SIMD, 128 VGPRs); wider rows keep 8 waves.
+constexpr int GV = 8;          // gathered rows per half-wave per step
+constexpr int STEP = 2 * GV;   // stored entries per step (both halves)
 template <int NT>
 struct ShortWaves {
     static constexpr int SW = NT <= 4 ? 16 : 8;
@@ -87,124 +85,180 @@ __device__ __forceinline__ void store_n(float* dst, const float (&src)[NT]) {
     }
 }
 
-// Sum over the 32 lanes of a half-wave (all lanes get the result).
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+// Cross-lane moves that stay in the vector ALU: DPP row operations (16-lane rows) and the lane-swap
+// instructions; none of them touches the LDS pipeline that the G reads and the broadcasts already load.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_ROR4 = 0x124;        // rotate within a row by 4 lanes
+constexpr int DPP_ROR8 = 0x128;        // rotate within a row by 8 lanes (= lane ^ 8)
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i within groups of 8
+
+// Lanes of the first row of each half-wave get a(self) + a(lane ^ 16), lanes of the second row b(self) + b(lane ^ 16).
+__device__ __forceinline__ float swap16_sum(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// GV values per lane -> after the butterfly, lane c of each half holds the 32-lane sum of value
-// (c >> 1) & 15 (GV = 16) or (c >> 2) & 7 (GV = 8).
-__device__ __forceinline__ float reduce_scatter(float (&p)[GV], int c) {
-    if constexpr (GV == 16) {
-        const bool up = (c & 16) != 0;
+// a(self) + a(lane ^ 32)
+__device__ __forceinline__ float swap32_sum(float a) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Sum over the 32 lanes of a half-wave (all lanes get the result).
+__device__ __forceinline__ float half_sum(float v) {
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_ROR4>(v);
+    v += dpp_mov<DPP_ROR8>(v);
+    return swap16_sum(v, v);
+}
+
+// GV = 8 values per lane -> lane c of each half ends with the 32-lane sum of value c >> 2.  Three halving
+// stages (lane bits 4, 3 and the mirror pairing that flips bits 0-2), then the quad is summed.
+__device__ __forceinline__ float reduce_scatter(const float (&p)[GV], int c) {
+    float q[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float keep = up ? p[i + 8] : p[i];
-            const float send = up ? p[i] : p[i + 8];
-            p[i] = keep + __shfl_xor(send, 16, 64);
-        }
-    }
-    constexpr int S1 = GV == 16 ? 8 : 16;  // lane bit that halves 8 values to 4
-    {
-        const bool up = (c & S1) != 0;
+    for (int i = 0; i < 4; ++i) q[i] = swap16_sum(p[i], p[i + 4]);
+    const bool b3 = (c & 8) != 0;
+    float r[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float keep = up ? p[i + 4] : p[i];
-            const float send = up ? p[i] : p[i + 4];
-            p[i] = keep + __shfl_xor(send, S1, 64);
-        }
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b3 ? q[i + 2] : q[i];
+        const float send = b3 ? q[i] : q[i + 2];
+        r[i] = keep + dpp_mov<DPP_ROR8>(send);
     }
-    {
-        const bool up = (c & (S1 >> 1)) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float keep = up ? p[i + 2] : p[i];
-            const float send = up ? p[i] : p[i + 2];
-            p[i] = keep + __shfl_xor(send, S1 >> 1, 64);
-        }
-    }
-    {
-        const bool up = (c & (S1 >> 2)) != 0;
-        const float keep = up ? p[1] : p[0];
-        const float send = up ? p[0] : p[1];
-        p[0] = keep + __shfl_xor(send, S1 >> 2, 64);
-    }
-    float d = p[0];
-#pragma unroll
-    for (int off = S1 >> 3; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+    const bool b2 = (c & 4) != 0;
+    const float keep = b2 ? r[1] : r[0];
+    const float send = b2 ? r[0] : r[1];
+    float d = keep + dpp_mov<DPP_HALF_MIRROR>(send);
+    d += dpp_mov<DPP_XOR1>(d);
+    d += dpp_mov<DPP_XOR2>(d);
     return d;
 }
 
-constexpr int DSH = GV == 16 ? 1 : 2;  // lane c holds the dot of gathered row (c >> DSH) of its half's step
+// Address of this lane's NT columns of gathered row `sel`.  Tables below 4 GiB carry `sel` as a byte offset
+// (one 32-bit add per gather, the base stays in scalar registers); larger ones as a row index.
+template <int NT, bool BIG>
+__device__ __forceinline__ const float* gather_ptr(const float* Y, int sel, int c) {
+    if constexpr (BIG) {
+        return Y + (int64_t)sel * (32 * NT) + c * NT;
+    } else {
+        return reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) +
+                                              ((uint32_t)sel + (uint32_t)(c * NT * 4)));
+    }
+}
 
-// acc (per half: the sum over that half's gathered rows) of
+// One step of a pass: stored entries [g0, g0 + 16), half h taking entry g0 + 2j + h as its j-th.  Entries
+// past the end of the row repeat the row's last entry (always loadable) and get coefficient zero, so no
+// load is conditional.  MODE 0: every entry slot of the step lies inside this wave's on-chip cache,
+// 1: the step straddles the end of the cache (g0 is then a compile-time constant), 2: it lies past it.
+template <int NT, int CAP, bool FIRST, bool BIG, int MODE>
+__device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[NT], const float* __restrict__ Y,
+                                            float* cache, int g0, int n, int cur_sel, float cur_dat, int selbase,
+                                            int coefbase, int h, int c) {
+    constexpr int F = 32 * NT;
+    constexpr int G0C = (CAP / STEP) * STEP;
+    float yv[GV][NT];
+    int sel[GV];
+    float* slot = cache + (g0 + h) * F + c * NT;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+        const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
+        if (FIRST || !inside) sel[j] = __builtin_amdgcn_ds_bpermute(selbase + 8 * j, cur_sel);
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+        const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
+        if (FIRST || !inside) {
+            load_n<NT>(yv[j], gather_ptr<NT, BIG>(Y, sel[j], c));
+        } else {
+            load_n<NT>(yv[j], slot + 2 * j * F);
+        }
+    }
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
+            if (inside) store_n<NT>(slot + 2 * j * F, yv[j]);
+        }
+    }
+    float part[GV];
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+        float s0 = yv[j][0] * v[0];
+        float s1 = NT > 1 ? yv[j][NT > 1 ? 1 : 0] * v[NT > 1 ? 1 : 0] : 0.f;
+#pragma unroll
+        for (int t = 2; t < NT; ++t) {
+            if (t & 1) s1 = fmaf(yv[j][t], v[t], s1);
+            else s0 = fmaf(yv[j][t], v[t], s0);
+        }
+        part[j] = s0 + s1;
+    }
+    const float d = reduce_scatter(part, c);
+    const int kkm = g0 + 2 * (c >> 2) + h;
+    const float w = fabsf(cur_dat) - 1.f;
+    float coef = FIRST ? ((cur_dat > 0.f ? cur_dat : 0.f) - w * d) : (w * d);
+    coef = kkm < n ? coef : 0.f;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+        const float cj = __int_as_float(__builtin_amdgcn_ds_bpermute(coefbase + 16 * j, __float_as_int(coef)));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = fmaf(cj, yv[j][t], acc[t]);
+    }
+}
+
+// acc (in every lane: the sum over all the row's stored entries) of
 //   FIRST:  (max(c,0) - (|c|-1)(y.v)) y        (start residual, v = x)
 //   else :  (|c|-1)(y.v) y                     (operator, v = p)
-template <int NT, int CAP, bool FIRST>
+// Lane l keeps, one step ahead, the index of entry g0 + (l & 15) and the confidence of the entry whose dot
+// product the reduction leaves in it.
+template <int NT, int CAP, bool FIRST, bool BIG>
 __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[NT], const int32_t* __restrict__ indices,
                                             const float* __restrict__ data, const float* __restrict__ Y, float* cache,
                                             int n, int lane, int h, int c) {
     constexpr int F = 32 * NT;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
-    for (int g0 = 0; g0 < n; g0 += 2 * GV) {
-        const bool need_idx = FIRST || (g0 + 2 * GV > CAP);
-        int myidx = 0;
-        if (need_idx) {
-            const int myk = g0 + (lane & 31);
-            if (myk < n) myidx = indices[myk];
+    const int e_idx = lane & 15;
+    const int e_dat = 2 * (c >> 2) + h;
+    const int selbase = ((lane & 32) | h) << 2;
+    const int coefbase = (lane & 32) << 2;
+    const int last = n - 1;
+    auto load_sel = [&](int g0) __attribute__((always_inline)) {
+        const int k = g0 + e_idx;
+        return indices[k < last ? k : last];
+    };
+    auto load_dat = [&](int g0) __attribute__((always_inline)) {
+        const int k = g0 + e_dat;
+        return data[k < last ? k : last];
+    };
+    int nxt_sel = load_sel(0);
+    float nxt_dat = load_dat(0);
+    for (int g0 = 0; g0 < n; g0 += STEP) {
+        // scaled to a byte offset only now, so that the load above stays in flight through the previous step
+        const int cur_sel = BIG ? nxt_sel : (int)((uint32_t)nxt_sel * (uint32_t)(F * 4));
+        const float cur_dat = nxt_dat;
+        if (g0 + STEP < n) {
+            nxt_sel = load_sel(g0 + STEP);
+            nxt_dat = load_dat(g0 + STEP);
         }
-        float yv[GV][NT];
-        float part[GV];
-#pragma unroll
-        for (int j = 0; j < GV; ++j) {
-            const int e = g0 + 2 * j;  // wave-uniform; this half takes e + h
-            const int kk = e + h;
-            const bool cached = !FIRST && (e < CAP);
-            if (cached) {
-                if (kk < n) {
-                    load_n<NT>(yv[j], cache + kk * F + c * NT);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) yv[j][t] = 0.f;
-                }
-            } else {
-                const int idx = __shfl(myidx, 2 * j + h, 64);
-                if (kk < n) {
-                    load_n<NT>(yv[j], Y + (int64_t)idx * F + c * NT);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) yv[j][t] = 0.f;
-                }
-                if (FIRST && e < CAP && kk < n) store_n<NT>(cache + kk * F + c * NT, yv[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < GV; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) s = fmaf(yv[j][t], v[t], s);
-            part[j] = s;
-        }
-        const float d = reduce_scatter(part, c);
-        const int kkm = g0 + 2 * (c >> DSH) + h;
-        float coef = 0.f;
-        if (kkm < n) {
-            const float cv = data[kkm];
-            const float w = fabsf(cv) - 1.f;
-            coef = FIRST ? ((cv > 0.f ? cv : 0.f) - w * d) : (w * d);
-        }
-#pragma unroll
-        for (int j = 0; j < GV; ++j) {
-            const float cj = __shfl(coef, (h << 5) | (j << DSH), 64);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = fmaf(cj, yv[j][t], acc[t]);
+        if (g0 + STEP <= CAP) {
+            sparse_step<NT, CAP, FIRST, BIG, 0>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+        } else if (CAP % STEP == 0 || g0 >= CAP) {
+            sparse_step<NT, CAP, FIRST, BIG, 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+        } else {
+            if constexpr (CAP % STEP != 0)
+                sparse_step<NT, CAP, FIRST, BIG, 1>(v, acc, Y, cache, (CAP / STEP) * STEP, n, cur_sel, cur_dat, selbase,
+                                                    coefbase, h, c);
         }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] += __shfl_xor(acc[t], 32, 64);
+    for (int t = 0; t < NT; ++t) acc[t] = swap32_sum(acc[t]);
 }
 
 // out = G v (both halves end with the full result); the k range is split over the halves.
@@ -233,10 +287,10 @@ __device__ __forceinline__ void symv_short(const float* Gs, float* vec, const fl
         }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) out[t] += __shfl_xor(out[t], 32, 64);
+    for (int t = 0; t < NT; ++t) out[t] = swap32_sum(out[t]);
 }
 
-template <int NT>
+template <int NT, bool BIG>
 __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, int64_t nrows, float* X, const float* __restrict__ Y, const float* __restrict__ G,
@@ -278,7 +332,7 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
         const int32_t* ind = indices + rs;
         const float* dat = data + rs;
 
-        sparse_pass<NT, CAP, true>(x, acc, ind, dat, Y, cache, n, lane, h, c);
+        sparse_pass<NT, CAP, true, BIG>(x, acc, ind, dat, Y, cache, n, lane, h, c);
         symv_short<NT>(Gs, vec, x, Ap, h, c);
         float part = 0.f;
 #pragma unroll
@@ -290,7 +344,7 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
         float rsold = half_sum(part);
         if (rsold < 1e-20f) continue;
         for (int it = 0; it < cg_steps; ++it) {
-            sparse_pass<NT, CAP, false>(p, acc, ind, dat, Y, cache, n, lane, h, c);
+            sparse_pass<NT, CAP, false, BIG>(p, acc, ind, dat, Y, cache, n, lane, h, c);
             symv_short<NT>(Gs, vec, p, Ap, h, c);
             part = 0.f;
 #pragma unroll
@@ -317,7 +371,7 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
     }
 }
 
-template <int NT>
+template <int NT, bool BIG>
 static int launch_short(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                         int64_t nrows, float* X, const float* Y, const float* G, int32_t short_max, int cg_steps,
                         hipStream_t stream) {
@@ -326,8 +380,8 @@ static int launch_short(const int64_t* indptr, const int32_t* indices, const flo
     static bool attr_done = false;  // idempotent; a race only repeats the call
     static int cus = 0;
     if (!attr_done) {
-        MIREC_HIP(hipFuncSetAttribute((const void*)als_short_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)L::BYTES));
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_short_kernel<NT, BIG>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
         int dev = 0;
         MIREC_HIP(hipGetDevice(&dev));
         MIREC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -336,22 +390,32 @@ static int launch_short(const int64_t* indptr, const int32_t* indices, const flo
     int64_t blocks = (nrows + SW - 1) / SW;
     if (blocks > cus) blocks = cus;
     if (blocks < 1) return MIREC_OK;
-    hipLaunchKernelGGL(als_short_kernel<NT>, dim3((unsigned)blocks), dim3(64 * SW), L::BYTES, stream, indptr, indices,
-                       data, row_begin, nrows, X, Y, G, short_max, cg_steps);
+    hipLaunchKernelGGL((als_short_kernel<NT, BIG>), dim3((unsigned)blocks), dim3(64 * SW), L::BYTES, stream, indptr,
+                       indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps);
     MIREC_LAUNCH_CHECK();
     return MIREC_OK;
 }
 
-int launch_als_short(int nt, const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
-                     int64_t nrows, float* X, const float* Y, const float* G, int32_t short_max, int cg_steps,
-                     hipStream_t stream) {
+template <int NT>
+static int launch_short_nt(int64_t y_rows, const int64_t* indptr, const int32_t* indices, const float* data,
+                           int64_t row_begin, int64_t nrows, float* X, const float* Y, const float* G,
+                           int32_t short_max, int cg_steps, hipStream_t stream) {
+    // byte offsets into the gathered table are kept in 32 bits while the whole table is addressable that way
+    const bool big = y_rows <= 0 || (uint64_t)y_rows * (32u * NT * 4u) > (1ull << 32);
+    return big ? launch_short<NT, true>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream)
+               : launch_short<NT, false>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
+}
+
+int launch_als_short(int nt, int64_t y_rows, const int64_t* indptr, const int32_t* indices, const float* data,
+                     int64_t row_begin, int64_t nrows, float* X, const float* Y, const float* G, int32_t short_max,
+                     int cg_steps, hipStream_t stream) {
     switch (nt) {
-        case 1: return launch_short<1>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
-        case 2: return launch_short<2>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
-        case 3: return launch_short<3>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
-        case 4: return launch_short<4>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
-        case 5: return launch_short<5>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
-        case 6: return launch_short<6>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
+        case 1: return launch_short_nt<1>(y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
+        case 2: return launch_short_nt<2>(y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
+        case 3: return launch_short_nt<3>(y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
+        case 4: return launch_short_nt<4>(y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
+        case 5: return launch_short_nt<5>(y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
+        case 6: return launch_short_nt<6>(y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
     }
     set_error("launch_als_short: unsupported width");
     return MIREC_E_UNSUPPORTED;

@@ -643,7 +643,7 @@ extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], 
 
 extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data,
                                     int64_t row_begin, int64_t row_end, int64_t nnz, float* X, const float* Y,
-                                    const float* G, int f, int cg_steps, const void* plan, int32_t chunk_nnz,
+                                    int64_t y_rows, const float* G, int f, int cg_steps, const void* plan, int32_t chunk_nnz,
                                     int32_t short_max, const int64_t host_counts[4], void* ws, size_t ws_bytes,
                                     mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -664,7 +664,7 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     const char* p = (const char*)plan;
     float* partials = (float*)ws;
     if (short_max >= 0 && host_counts[3] > 0) {
-        const int rc = launch_als_short(f / 32, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps,
+        const int rc = launch_als_short(f / 32, y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps,
                                         stream);
         if (rc != MIREC_OK) return rc;
     }

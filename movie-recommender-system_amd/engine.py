@@ -166,12 +166,14 @@ class SweepPlan:
         return int(self.counts[3])
 
     def sweep(self, X_rows: torch.Tensor, Y: torch.Tensor, G: torch.Tensor, cg_steps: int = 3,
-              phase: str = "both") -> None:
+              phase: str = "both", y_rows: Optional[int] = None) -> None:
         """Solve the plan's rows in place: ``X_rows`` is the [nrows, f] block of
         the factor matrix that belongs to these CSR rows.  ``phase`` lets a
         profiler bracket the kernels of a sweep separately: "short" launches
         only the matrix-free kernel, "main" only the Gram+CG kernel, "finalize"
-        only the split-row reduction (which must follow "main" on the stream)."""
+        only the split-row reduction (which must follow "main" on the stream).
+        ``y_rows`` overrides the row count of ``Y`` passed to the library (0 =
+        "not known", which selects 64-bit addressing of the gathered table)."""
         lib = _lib.require()
         csr = self.csr
         assert X_rows.shape == (csr.shape[0], self.f) and X_rows.is_contiguous()
@@ -184,7 +186,7 @@ class SweepPlan:
             if phase != "short":
                 short_max = -1
         _lib.check(lib.mirec_als_half_sweep(_ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.data), 0, csr.shape[0],
-                                            csr.nnz, _ptr(X_rows), _ptr(Y), _ptr(G), self.f, int(cg_steps),
+                                            csr.nnz, _ptr(X_rows), _ptr(Y), int(Y.shape[0] if y_rows is None else y_rows), _ptr(G), self.f, int(cg_steps),
                                             _ptr(self.plan), self.chunk_nnz, short_max, counts, _ptr(self.ws),
                                             self.ws.numel(), _stream_ptr()), "mirec_als_half_sweep")
 

@@ -90,6 +90,10 @@ def test_half_sweep_matches_oracle(dev, f, chunk, short_max):
     dX2 = torch.from_numpy(X).to(dev)
     plan.sweep(dX2, dY, G, 3)
     assert np.array_equal(dX2.cpu().numpy(), out)
+    # tables of 4 GiB and more are addressed by row index instead of 32-bit byte offsets: same arithmetic
+    dX3 = torch.from_numpy(X).to(dev)
+    plan.sweep(dX3, dY, G, 3, y_rows=0)
+    assert np.array_equal(dX3.cpu().numpy(), out)
 
 
 def test_half_sweep_row_range(dev):
