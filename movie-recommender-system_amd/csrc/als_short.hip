@@ -26,6 +26,9 @@ namespace mirec {
 // issue and latency, not by registers well spent: measured on the 1 M x 27 k user half-sweep at F = 128,
 // (waves, rows/step) = (8,16) 12.8 ms, (8,8) 14.3, (12,8) 10.7, (16,8) 10.5 -- so up to F = 128 the kernel runs
 // 16 waves (4 per SIMD, 128 VGPRs); wider rows keep 8 waves.
+#ifndef MIREC_SYMV_UNROLL
+#define MIREC_SYMV_UNROLL 8
+#endif
 constexpr int GV = 8;          // gathered rows per half-wave per step
 constexpr int STEP = 2 * GV;   // stored entries per step (both halves)
 template <int NT>
@@ -272,7 +275,7 @@ __device__ __forceinline__ void symv_short(const float* Gs, float* vec, const fl
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t] = 0.f;
     const int k0 = h * (F / 2);
-#pragma unroll 2
+#pragma unroll MIREC_SYMV_UNROLL
     for (int k = k0; k < k0 + F / 2; k += 4) {
         const float4 pk = *reinterpret_cast<const float4*>(vec + k);
         float g[4][NT];

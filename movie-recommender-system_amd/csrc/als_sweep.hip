@@ -1,15 +1,22 @@
-// ALS half-sweep, explicit form: per-row confidence-weighted Gram on the fp32
-// matrix cores, then a warm-started conjugate-gradient solve (3 steps by default).
+// ALS half-sweep, explicit form: per-row confidence-weighted Gram on the matrix
+// cores, then a warm-started conjugate-gradient solve (3 steps by default).
 //
 // Work unit = one "chunk": a run of stored entries of one CSR row (rows longer
 // than chunk_nnz are cut into up to 32 equal chunks).  A workgroup of NT
-// wavefronts (F = 32*NT factor columns) gathers the chunk's factor rows 64 at a
+// wavefronts (F = 32*NT factor columns) gathers the chunk's factor rows 32 at a
 // time through a double-buffered LDS tile -- the next tile's gathers and the
 // indices of the one after are in flight while the current one is consumed --
 // and accumulates
-//     A += sum_k (|c_k|-1) y_k y_k^T      (v_mfma_f32_16x16x4_f32, only the
-//                                          tiles on or above the diagonal)
-//     b += sum_k max(c_k,0) y_k
+//     A += sum_k (|c_k|-1) y_k y_k^T      (only the 16x16 tiles on or above the
+//                                          diagonal)
+//     b += sum_k max(c_k,0) y_k           (fp32 vector ALU)
+// The Gram runs on v_mfma_f32_16x16x32_bf16 at fp32 accuracy: each scaled row
+// z_k = sqrt(||c_k|-1|) y_k is split exactly into three bf16 planes
+// z = hi + mid + lo (8 + 8 + 8 significant bits) and a tile accumulates the six
+// plane products down to hi*lo; the dropped ones are below 2^-26 of the term
+// (measured 2.7e-8 of sum|products| against 1.1e-7 for an fp32 fma chain), at
+// 6/16 of the matrix-core time of the fp32 instruction.  An entry with
+// |c_k| < 1 has a negative weight: its sign is applied to the left operand.
 // Rows that fit one chunk are finished in the same workgroup: A + G is written
 // to LDS (aliasing the gather tiles) and wave 0 runs the CG steps on it.  Rows
 // split over several chunks store their partial (A, b) to a workspace slot; a
@@ -19,7 +26,7 @@
 
 namespace mirec {
 
-constexpr int TR = 64;               // gathered rows per LDS tile
+constexpr int TR = 32;               // gathered rows per LDS tile = one k-step of the bf16 MFMA
 constexpr int MAX_ROW_CHUNKS = 32;   // a row is split into at most this many chunks
 
 // ---------------------------------------------------------------- plan -----
@@ -240,25 +247,38 @@ __device__ void cg_solve_wave(const float* A, const float* b, float* vec, float*
 //   diagonal are accumulated (NB = F/16 bands).  Wave w of the NT waves owns
 //   band-rows w and NB-1-w: (NB-w) + (w+1) = NB+1 tiles each, so the matrix
 //   pipes of the four SIMDs are evenly loaded.
-//   Gathered rows are staged 64 at a time in LDS with a row stride of F+16
-//   floats, which puts the four rows of one MFMA k-step on disjoint banks.
+//   A tile of 32 gathered rows sits in LDS as three bf16 planes [column][32
+//   entries] (64-byte rows of four 16-byte chunks, chunk q of column c stored
+//   at position q ^ ((c >> 1) & 3)): lane (m, q) of an MFMA operand reads the
+//   eight entries 8q..8q+7 of column 16*band + m with one conflict-free
+//   ds_read_b128, and the same image serves as left and right operand.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // one MFMA operand (8 bf16) = one LDS chunk
+
 template <int NT>
 struct GramCfg {
     static constexpr int F = 32 * NT;
     static constexpr int NB = 2 * NT;
-    static constexpr int LDF = F + 16;
     static constexpr int NTHR = 64 * NT;
     static constexpr int NTILES = NB * (NB + 1) / 2;
-    static constexpr int TILE_FLOATS = TR * LDF;
+    static constexpr int PLANE_BYTES = F * 64;
+    static constexpr int TILE_BYTES = 3 * PLANE_BYTES;
+    static constexpr int TILE_FLOATS = TILE_BYTES / 4;
     static constexpr int BIGN = (F * F > 2 * TILE_FLOATS) ? F * F : 2 * TILE_FLOATS;
     static constexpr int PART_STRIDE = NTILES * 256 + F;  // floats of one partial-result slot
-    static constexpr int FLOATS = BIGN + 2 * TR * 2 + 2 * F;
+    // LDS map (floats): [0, BIGN) gather tiles / A; sign masks of the two tiles; b partials of the four entry
+    // groups; b; the CG work vector
+    static constexpr int SMASK = BIGN;
+    static constexpr int BRED = SMASK + 2 * 16;
+    static constexpr int BVEC = BRED + 4 * F;
+    static constexpr int VEC = BVEC + F;
+    static constexpr int FLOATS = VEC + F;
     static constexpr size_t BYTES = (size_t)FLOATS * 4;
     // first tile id of band-row b in the row-major enumeration of the upper triangle
     static constexpr int row_start(int b) { return b * NB - b * (b - 1) / 2; }
 };
-
-constexpr int RPT = TR / 8;  // gathered rows per thread per tile (8 rows per pass of the workgroup)
 
 // Accumulators of wave W: band-row W (tiles (W, W..NB-1)) and band-row NB-1-W (tiles (R1, R1..NB-1)).
 template <int NT, int W>
@@ -269,43 +289,81 @@ struct WaveAcc {
     static constexpr int N1 = W + 1;
     f32x4 a0[N0];
     f32x4 a1[N1];
-    float b0, b1;
 };
 
-// One LDS tile of 64 gathered rows: 16 k-steps of v_mfma_f32_16x16x4_f32.  Lane l feeds row 4s + (l>>4)
-// of the step and column (l&15) of each band.  Operands of step s+1 are read while step s's MFMAs run.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// (x0, x1) -> three words of packed bf16 pairs with hi + mid + lo == x exactly to 24 bits (round to nearest
+// at every level; each remainder is exact in fp32).
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(hi << 16);
+    float r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(mid << 16);
+    r1 -= __uint_as_float(mid & 0xffff0000u);
+    lo = cvt_pk_bf16(r0, r1);
+}
+
+__device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}
+
+// acc += l^T r over the 32 entries of the tile, planes {hi, mid, lo}; smallest products first.
+__device__ __forceinline__ f32x4 mma6(f32x4 acc, const u32x4 (&l)[3], const u32x4 (&r)[3]) {
+    acc = mma_bf16(l[2], r[0], acc);
+    acc = mma_bf16(l[0], r[2], acc);
+    acc = mma_bf16(l[1], r[1], acc);
+    acc = mma_bf16(l[1], r[0], acc);
+    acc = mma_bf16(l[0], r[1], acc);
+    acc = mma_bf16(l[0], r[0], acc);
+    return acc;
+}
+
+// One LDS tile of 32 gathered rows: the wave's NB+1 tiles, six MFMAs each.
 template <int NT, int W>
-__device__ __forceinline__ void gram_tile(const float* tl, const float2* wt, WaveAcc<NT, W>& A, int lane) {
+__device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, WaveAcc<NT, W>& A, int lane) {
     using C = GramCfg<NT>;
     using WA = WaveAcc<NT, W>;
-    constexpr int N0 = WA::N0, N1 = WA::N1, R1 = WA::R1;
-    const int q = lane >> 4, i = lane & 15;
-    const float* base = tl + q * C::LDF + W * 16 + i;
-    float bq[2][N0];
-    float2 wq[2];
+    constexpr int N0 = WA::N0, R1 = WA::R1;
+    const int m = lane & 15, q = lane >> 4;
+    const char* base = tl + m * 64 + ((q ^ ((m >> 1) & 3)) << 4);
+    auto ld = [&](int band, int plane) __attribute__((always_inline)) {
+        return *reinterpret_cast<const u32x4*>(base + plane * C::PLANE_BYTES + band * 1024);
+    };
+    u32x4 r0[3], r1[3], l0[3], l1[3];
 #pragma unroll
-    for (int j = 0; j < N0; ++j) bq[0][j] = base[j * 16];
-    wq[0] = wt[q];
+    for (int p = 0; p < 3; ++p) {
+        r0[p] = ld(W, p);
+        r1[p] = ld(R1, p);
+    }
+    // sign words of this lane's eight entries (bit 15 / 31 set where the entry's weight is negative)
+    const u32x4 sg = *reinterpret_cast<const u32x4*>(sm + 4 * q);
+    const bool flip = __builtin_amdgcn_ballot_w64((sg[0] | sg[1] | sg[2] | sg[3]) != 0u) != 0ull;
 #pragma unroll
-    for (int s = 0; s < TR / 4; ++s) {
-        if (s + 1 < TR / 4) {
-            const float* nb = base + (s + 1) * 4 * C::LDF;
+    for (int p = 0; p < 3; ++p) {
+        l0[p] = r0[p];
+        l1[p] = r1[p];
+    }
+    if (flip) {
 #pragma unroll
-            for (int j = 0; j < N0; ++j) bq[(s + 1) & 1][j] = nb[j * 16];
-            wq[(s + 1) & 1] = wt[(s + 1) * 4 + q];
+        for (int p = 0; p < 3; ++p) {
+            l0[p] ^= sg;
+            l1[p] ^= sg;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        const float(&b)[N0] = bq[s & 1];
-        const float2 wc = wq[s & 1];
-        const float a0 = b[0] * wc.x;
-        const float a1 = b[R1 - W] * wc.x;
+    }
 #pragma unroll
-        for (int j = 0; j < N0; ++j) A.a0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], A.a0[j], 0, 0, 0);
+    for (int j = 0; j < N0; ++j) {
+        const int band = W + j;
+        u32x4 rb[3];
 #pragma unroll
-        for (int j = 0; j < N1; ++j) A.a1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[R1 - W + j], A.a1[j], 0, 0, 0);
-        A.b0 = fmaf(wc.y, b[0], A.b0);
-        A.b1 = fmaf(wc.y, b[R1 - W], A.b1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int p = 0; p < 3; ++p) rb[p] = (j == 0) ? r0[p] : (band == R1 ? r1[p] : ld(band, p));
+        A.a0[j] = mma6(A.a0[j], l0, rb);
+        if (band >= R1) A.a1[band - R1] = mma6(A.a1[band - R1], l1, rb);
     }
 }
 
@@ -318,72 +376,99 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
     using WA = WaveAcc<NT, W>;
     constexpr int F = C::F;
     float* big = smem;
-    float2* wts = reinterpret_cast<float2*>(smem + C::BIGN);
-    float* bvec = smem + C::BIGN + 2 * TR * 2;
+    char* tiles = reinterpret_cast<char*>(smem);
+    uint32_t* smask = reinterpret_cast<uint32_t*>(smem + C::SMASK);
+    float* bred = smem + C::BRED;
+    float* bvec = smem + C::BVEC;
 
     WA A;
 #pragma unroll
     for (int j = 0; j < WA::N0; ++j) A.a0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < WA::N1; ++j) A.a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    A.b0 = 0.f;
-    A.b1 = 0.f;
 
-    // Staging registers of this thread: RPT gathered rows (one float4 column group each), their indices one
-    // tile further ahead, and the confidence of tile row `tid`.  Index loads are unconditional (clamped to
-    // the chunk's last entry): rows past the end get weight 0.  The confidence stays raw until store time so
-    // that nothing waits on its load while the gathers behind it are in flight.
+    // Staging of this thread: columns 2*c2, 2*c2+1 of the eight entries 8*eg .. 8*eg+7 of a tile (so that a
+    // column's eight entries make one 16-byte LDS chunk), their indices and confidences one tile further
+    // ahead.  Index loads are unconditional (clamped to the chunk's last entry); entries past the end get
+    // confidence -1: weight 0 and no contribution to b.
     const int ntiles = (int)((ke - ks + TR - 1) / TR);
-    const int c4 = tid % (8 * NT);
-    const int rsub = tid / (8 * NT);
-    int idx[RPT];
-    f32x4 sv[RPT];
-    float craw = 0.f;
-    bool cvalid = false;
-    auto load_idx = [&](int64_t k0) __attribute__((always_inline)) {
+    const int c2 = tid % (F / 2);
+    const int eg = tid / (F / 2);
+    int idx[8];
+    float dnext[8], dcur[8];
+    f32x2 yv[8];
+    float bacc0 = 0.f, bacc1 = 0.f;
+    auto load_meta = [&](int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < RPT; ++p) {
-            const int64_t k = k0 + p * 8 + rsub;
-            idx[p] = indices[k < ke ? k : ke - 1];
+        for (int e = 0; e < 8; ++e) {
+            const int64_t k = k0 + 8 * eg + e;
+            const int64_t kk = k < ke ? k : ke - 1;
+            idx[e] = indices[kk];
+            const float d = data[kk];
+            dnext[e] = k < ke ? d : -1.f;
         }
     };
-    auto load_rows = [&](int64_t k0) __attribute__((always_inline)) {
+    auto load_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < RPT; ++p) sv[p] = *reinterpret_cast<const f32x4*>(Y + (int64_t)idx[p] * F + 4 * c4);
-        if (tid < TR) {
-            const int64_t k = k0 + tid;
-            craw = data[k < ke ? k : ke - 1];
-            cvalid = k < ke;
+        for (int e = 0; e < 8; ++e) {
+            yv[e] = *reinterpret_cast<const f32x2*>(Y + (int64_t)idx[e] * F + 2 * c2);
+            dcur[e] = dnext[e];
         }
     };
-    auto store_tile = [&](float* tile, float2* wt) __attribute__((always_inline)) {
+    const int wbase = c2 * 128 + ((eg ^ (c2 & 3)) << 4);
+    auto store_tile = [&](char* tile, uint32_t* sm) __attribute__((always_inline)) {
+        float sw[8];
+        uint32_t neg[8];
 #pragma unroll
-        for (int p = 0; p < RPT; ++p) *reinterpret_cast<f32x4*>(tile + (p * 8 + rsub) * C::LDF + 4 * c4) = sv[p];
-        if (tid < TR)
-            wt[tid] = cvalid ? make_float2(fabsf(craw) - 1.f, craw > 0.f ? craw : 0.f) : make_float2(0.f, 0.f);
+        for (int e = 0; e < 8; ++e) {
+            const float w = fabsf(dcur[e]) - 1.f;
+            sw[e] = __builtin_amdgcn_sqrtf(fabsf(w));
+            neg[e] = w < 0.f ? 1u : 0u;
+            const float cp = dcur[e] > 0.f ? dcur[e] : 0.f;
+            bacc0 = fmaf(cp, yv[e][0], bacc0);
+            bacc1 = fmaf(cp, yv[e][1], bacc1);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 hi, mid, lo;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t h, m, l;
+                split3(sw[2 * d] * yv[2 * d][t], sw[2 * d + 1] * yv[2 * d + 1][t], h, m, l);
+                hi[d] = h;
+                mid[d] = m;
+                lo[d] = l;
+            }
+            char* dst = tile + wbase + t * 64;
+            *reinterpret_cast<u32x4*>(dst) = hi;
+            *reinterpret_cast<u32x4*>(dst + C::PLANE_BYTES) = mid;
+            *reinterpret_cast<u32x4*>(dst + 2 * C::PLANE_BYTES) = lo;
+        }
+        if (c2 == 0) {
+            u32x4 sgn;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) sgn[d] = (neg[2 * d] << 15) | (neg[2 * d + 1] << 31);
+            *reinterpret_cast<u32x4*>(sm + 4 * eg) = sgn;
+        }
     };
 
-    load_idx(ks);
-    load_rows(ks);
-    if (ntiles > 1) load_idx(ks + TR);
+    load_meta(ks);
+    load_rows();
+    if (ntiles > 1) load_meta(ks + TR);
     for (int tile = 0; tile < ntiles; ++tile) {
-        float* tl = big + (tile & 1) * C::TILE_FLOATS;
-        float2* wt = wts + (tile & 1) * TR;
-        store_tile(tl, wt);
+        char* tl = tiles + (tile & 1) * C::TILE_BYTES;
+        uint32_t* sm = smask + (tile & 1) * 16;
+        store_tile(tl, sm);
         __syncthreads();
         // gathers of the next tile (their indices arrived a tile ago), then the indices of the one after
-        if (tile + 1 < ntiles) load_rows(ks + (int64_t)(tile + 1) * TR);
-        if (tile + 2 < ntiles) load_idx(ks + (int64_t)(tile + 2) * TR);
+        if (tile + 1 < ntiles) load_rows();
+        if (tile + 2 < ntiles) load_meta(ks + (int64_t)(tile + 2) * TR);
         __builtin_amdgcn_sched_barrier(0);
-        gram_tile<NT, W>(tl, wt, A, lane);
+        gram_tile<NT, W>(tl, sm, A, lane);
     }
-    // column sums of the b partials over the four row groups of a k-step
-    float b0 = A.b0, b1 = A.b1;
-    b0 += __shfl_xor(b0, 16, 64);
-    b0 += __shfl_xor(b0, 32, 64);
-    b1 += __shfl_xor(b1, 16, 64);
-    b1 += __shfl_xor(b1, 32, 64);
-    __syncthreads();  // every wave is done with the gather tiles that alias `big`
+    bred[eg * F + 2 * c2] = bacc0;
+    bred[eg * F + 2 * c2 + 1] = bacc1;
+    __syncthreads();  // every wave is done with the gather tiles that alias `big`; the b partials are visible
 
     const int q = lane >> 4, i = lane & 15;
     if (single) {
@@ -406,10 +491,7 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
                 big[rr * F + cc] = v + G[rr * F + cc];
                 if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
             }
-        if (q == 0) {
-            bvec[W * 16 + i] = b0;
-            bvec[WA::R1 * 16 + i] = b1;
-        }
+        if (tid < F) bvec[tid] = (bred[tid] + bred[F + tid]) + (bred[2 * F + tid] + bred[3 * F + tid]);
     } else {
         // upper tiles only, tile-major: slot[tile][row][col]
 #pragma unroll
@@ -420,10 +502,8 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
         for (int j = 0; j < WA::N1; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) P[(C::row_start(WA::R1) + j) * 256 + (q * 4 + e) * 16 + i] = A.a1[j][e];
-        if (q == 0) {
-            P[C::NTILES * 256 + W * 16 + i] = b0;
-            P[C::NTILES * 256 + WA::R1 * 16 + i] = b1;
-        }
+        if (tid < F)
+            P[C::NTILES * 256 + tid] = (bred[tid] + bred[F + tid]) + (bred[2 * F + tid] + bred[3 * F + tid]);
     }
 }
 
@@ -443,8 +523,8 @@ __global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
     constexpr int F = C::F;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* big = smem;
-    float* bvec = smem + C::BIGN + 2 * TR * 2;
-    float* vec = bvec + F;
+    float* bvec = smem + C::BVEC;
+    float* vec = smem + C::VEC;
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -498,8 +578,8 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
     constexpr int NB = C::NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* big = smem;
-    float* bvec = smem + C::BIGN + 2 * TR * 2;
-    float* vec = bvec + F;
+    float* bvec = smem + C::BVEC;
+    float* vec = smem + C::VEC;
 
     const int tid = threadIdx.x;
     const int r = multi_row[blockIdx.x];
