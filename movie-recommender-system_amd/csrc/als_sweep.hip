@@ -22,6 +22,8 @@
 // split over several chunks store their partial (A, b) to a workspace slot; a
 // second kernel sums the slots in chunk order (fixed, so results are
 // reproducible) and runs the same CG.
+#include <type_traits>
+
 #include "als_internal.h"
 
 namespace mirec {
@@ -296,16 +298,20 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
-// (x0, x1) -> three words of packed bf16 pairs with hi + mid + lo == x exactly to 24 bits (round to nearest
-// at every level; each remainder is exact in fp32).
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    hi = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(hi << 16);
-    float r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-    mid = cvt_pk_bf16(r0, r1);
-    r0 -= __uint_as_float(mid << 16);
-    r1 -= __uint_as_float(mid & 0xffff0000u);
-    lo = cvt_pk_bf16(r0, r1);
+// Two entries (a, b) x two columns (x, y) -> for each column three words of packed bf16 pairs (entry a in the
+// low half) with hi + mid + lo == value exactly to 24 bits: round to nearest at every level, each remainder
+// exact in fp32.  The remainders are formed per entry on column pairs (packed fp32 ops on adjacent registers).
+__device__ __forceinline__ void split3x2(f32x2 a, f32x2 b, uint32_t (&hi)[2], uint32_t (&mid)[2], uint32_t (&lo)[2]) {
+    hi[0] = cvt_pk_bf16(a[0], b[0]);
+    hi[1] = cvt_pk_bf16(a[1], b[1]);
+    a -= f32x2{__uint_as_float(hi[0] << 16), __uint_as_float(hi[1] << 16)};
+    b -= f32x2{__uint_as_float(hi[0] & 0xffff0000u), __uint_as_float(hi[1] & 0xffff0000u)};
+    mid[0] = cvt_pk_bf16(a[0], b[0]);
+    mid[1] = cvt_pk_bf16(a[1], b[1]);
+    a -= f32x2{__uint_as_float(mid[0] << 16), __uint_as_float(mid[1] << 16)};
+    b -= f32x2{__uint_as_float(mid[0] & 0xffff0000u), __uint_as_float(mid[1] & 0xffff0000u)};
+    lo[0] = cvt_pk_bf16(a[0], b[0]);
+    lo[1] = cvt_pk_bf16(a[1], b[1]);
 }
 
 __device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -324,7 +330,9 @@ __device__ __forceinline__ f32x4 mma6(f32x4 acc, const u32x4 (&l)[3], const u32x
     return acc;
 }
 
-// One LDS tile of 32 gathered rows: the wave's NB+1 tiles, six MFMAs each.
+// One LDS tile of 32 gathered rows: the wave's NB+1 tiles, six MFMAs each.  The left operands are the right
+// ones with the sign of every negative-weight entry flipped (a wave-uniform branch skips that for tiles
+// without such entries).
 template <int NT, int W>
 __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, WaveAcc<NT, W>& A, int lane) {
     using C = GramCfg<NT>;
@@ -367,8 +375,9 @@ __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, Wa
     }
 }
 
-// Everything a wave does for one chunk once its wave index is a compile-time constant.
-template <int NT, int W>
+// Everything a wave does for one chunk once its wave index is a compile-time constant.  BIG: the gathered
+// table spans 4 GiB or more, so rows are addressed by 64-bit arithmetic instead of 32-bit byte offsets.
+template <int NT, int W, bool BIG>
 __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indices, const float* __restrict__ data,
                                                 const float* __restrict__ Y, const float* __restrict__ G, int64_t ks,
                                                 int64_t ke, float* smem, bool single, float* P, int tid, int lane) {
@@ -388,81 +397,118 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
     for (int j = 0; j < WA::N1; ++j) A.a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Staging of this thread: columns 2*c2, 2*c2+1 of the eight entries 8*eg .. 8*eg+7 of a tile (so that a
-    // column's eight entries make one 16-byte LDS chunk), their indices and confidences one tile further
-    // ahead.  Index loads are unconditional (clamped to the chunk's last entry); entries past the end get
-    // confidence -1: weight 0 and no contribution to b.
+    // column's eight entries make one 16-byte LDS chunk).  Gathered rows and confidences are loaded one tile
+    // ahead, indices two tiles ahead; each set is overwritten only after its consumer ran, so one register set
+    // of each suffices.  Entries past the end of the chunk repeat its last index and get confidence -1:
+    // weight 0 and no contribution to b.
     const int ntiles = (int)((ke - ks + TR - 1) / TR);
     const int c2 = tid % (F / 2);
     const int eg = tid / (F / 2);
     int idx[8];
-    float dnext[8], dcur[8];
+    float dd[8];
     f32x2 yv[8];
     float bacc0 = 0.f, bacc1 = 0.f;
-    auto load_meta = [&](int64_t k0) __attribute__((always_inline)) {
+    const int32_t* ip = indices + ks + 8 * eg;
+    const float* dp = data + ks + 8 * eg;
+    const int nent = (int)(ke - ks);
+    int left_i = nent - 8 * eg;  // entries of the chunk from ip on (may be <= 0 in the last tile)
+    int left_d = left_i;
+    int tile_i = 0, tile_d = 0;  // tiles whose indices / rows have been requested (wave-uniform)
+    auto load_idx = [&]() __attribute__((always_inline)) {
+        if ((tile_i + 1) * TR <= nent) {  // whole tile inside the chunk (uniform)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t k = k0 + 8 * eg + e;
-            const int64_t kk = k < ke ? k : ke - 1;
-            idx[e] = indices[kk];
-            const float d = data[kk];
-            dnext[e] = k < ke ? d : -1.f;
+            for (int e = 0; e < 8; ++e) idx[e] = ip[e];
+        } else {
+            const int last = left_i - 1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) idx[e] = ip[e < last ? e : last];
         }
+        ip += TR;
+        left_i -= TR;
+        ++tile_i;
     };
+    const uint32_t lane_off = (uint32_t)c2 * 8u;
     auto load_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            yv[e] = *reinterpret_cast<const f32x2*>(Y + (int64_t)idx[e] * F + 2 * c2);
-            dcur[e] = dnext[e];
+            if constexpr (BIG) {
+                yv[e] = *reinterpret_cast<const f32x2*>(Y + (int64_t)idx[e] * F + 2 * c2);
+            } else {
+                yv[e] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(Y) +
+                                                        ((uint32_t)idx[e] * (uint32_t)(F * 4) + lane_off));
+            }
         }
+        if ((tile_d + 1) * TR <= nent) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dd[e] = dp[e];
+        } else {
+            const int last = left_d - 1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = dp[e < last ? e : last];
+                dd[e] = e <= last ? v : -1.f;
+            }
+        }
+        dp += TR;
+        left_d -= TR;
+        ++tile_d;
     };
     const int wbase = c2 * 128 + ((eg ^ (c2 & 3)) << 4);
     auto store_tile = [&](char* tile, uint32_t* sm) __attribute__((always_inline)) {
-        float sw[8];
-        uint32_t neg[8];
+        float sw[8], w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float w = fabsf(dcur[e]) - 1.f;
-            sw[e] = __builtin_amdgcn_sqrtf(fabsf(w));
-            neg[e] = w < 0.f ? 1u : 0u;
-            const float cp = dcur[e] > 0.f ? dcur[e] : 0.f;
+            w[e] = fabsf(dd[e]) - 1.f;
+            sw[e] = __builtin_amdgcn_sqrtf(fabsf(w[e]));
+            // max(c, 0) on the bit pattern: positive floats order like integers, everything else is <= 0
+            const int di = __float_as_int(dd[e]);
+            const float cp = __int_as_float(di > 0 ? di : 0);
             bacc0 = fmaf(cp, yv[e][0], bacc0);
             bacc1 = fmaf(cp, yv[e][1], bacc1);
         }
+        // b is final for this tile before the next gathers overwrite yv
+        asm volatile("" : "+v"(bacc0), "+v"(bacc1));
+        u32x4 hi[2], mid[2], lo[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t h[2], m[2], l[2];
+            split3x2(yv[2 * q] * sw[2 * q], yv[2 * q + 1] * sw[2 * q + 1], h, m, l);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                hi[t][q] = h[t];
+                mid[t][q] = m[t];
+                lo[t][q] = l[t];
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            u32x4 hi, mid, lo;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                uint32_t h, m, l;
-                split3(sw[2 * d] * yv[2 * d][t], sw[2 * d + 1] * yv[2 * d + 1][t], h, m, l);
-                hi[d] = h;
-                mid[d] = m;
-                lo[d] = l;
-            }
             char* dst = tile + wbase + t * 64;
-            *reinterpret_cast<u32x4*>(dst) = hi;
-            *reinterpret_cast<u32x4*>(dst + C::PLANE_BYTES) = mid;
-            *reinterpret_cast<u32x4*>(dst + 2 * C::PLANE_BYTES) = lo;
+            *reinterpret_cast<u32x4*>(dst) = hi[t];
+            *reinterpret_cast<u32x4*>(dst + C::PLANE_BYTES) = mid[t];
+            *reinterpret_cast<u32x4*>(dst + 2 * C::PLANE_BYTES) = lo[t];
         }
         if (c2 == 0) {
+            // sign bits of the weights of entries (2q, 2q+1) at bits 15 and 31 of word q
             u32x4 sgn;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) sgn[d] = (neg[2 * d] << 15) | (neg[2 * d + 1] << 31);
+            for (int q = 0; q < 4; ++q)
+                sgn[q] = __builtin_amdgcn_perm(__float_as_uint(w[2 * q + 1]), __float_as_uint(w[2 * q]), 0x07060302u) &
+                         0x80008000u;
             *reinterpret_cast<u32x4*>(sm + 4 * eg) = sgn;
         }
     };
 
-    load_meta(ks);
+    load_idx();
     load_rows();
-    if (ntiles > 1) load_meta(ks + TR);
+    if (ntiles > 1) load_idx();
     for (int tile = 0; tile < ntiles; ++tile) {
         char* tl = tiles + (tile & 1) * C::TILE_BYTES;
         uint32_t* sm = smask + (tile & 1) * 16;
         store_tile(tl, sm);
         __syncthreads();
-        // gathers of the next tile (their indices arrived a tile ago), then the indices of the one after
+        // gathers and confidences of the next tile (its indices arrived a tile ago), then the indices of the one after
         if (tile + 1 < ntiles) load_rows();
-        if (tile + 2 < ntiles) load_meta(ks + (int64_t)(tile + 2) * TR);
+        if (tile + 2 < ntiles) load_idx();
         __builtin_amdgcn_sched_barrier(0);
         gram_tile<NT, W>(tl, sm, A, lane);
     }
@@ -513,7 +559,7 @@ __device__ __forceinline__ int64_t chunk_len(int64_t n, int nch) {
     return (per + TR - 1) / TR * TR;
 }
 
-template <int NT>
+template <int NT, bool BIG>
 __global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G,
@@ -554,12 +600,12 @@ __global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
     }
 
     switch (w) {
-        case 0: gram_chunk_wave<NT, 0>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 1: if constexpr (NT > 1) gram_chunk_wave<NT, 1>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 2: if constexpr (NT > 2) gram_chunk_wave<NT, 2>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 3: if constexpr (NT > 3) gram_chunk_wave<NT, 3>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 4: if constexpr (NT > 4) gram_chunk_wave<NT, 4>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 5: if constexpr (NT > 5) gram_chunk_wave<NT, 5>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 0: gram_chunk_wave<NT, 0, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 1: if constexpr (NT > 1) gram_chunk_wave<NT, 1, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 2: if constexpr (NT > 2) gram_chunk_wave<NT, 2, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 3: if constexpr (NT > 3) gram_chunk_wave<NT, 3, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 4: if constexpr (NT > 4) gram_chunk_wave<NT, 4, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 5: if constexpr (NT > 5) gram_chunk_wave<NT, 5, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
     }
     if (single) {
         __syncthreads();
@@ -620,7 +666,7 @@ template <int NT>
 static int launch_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                         float* X, const float* Y, const float* G, int cg_steps, const char* plan,
                         const PlanLayout& L, int32_t chunk_nnz, const int64_t counts[3], float* partials,
-                        hipStream_t stream) {
+                        int64_t y_rows, hipStream_t stream) {
     using S = GramCfg<NT>;
     const int32_t* chunk_ptr = (const int32_t*)(plan + L.chunk_ptr);
     const int32_t* mslot_ptr = (const int32_t*)(plan + L.mslot_ptr);
@@ -628,15 +674,25 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
     const int32_t* multi_row = (const int32_t*)(plan + L.multi_row);
     static bool attr_done = false;  // idempotent; a race only repeats the call
     if (!attr_done) {
-        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT>,
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
         MIREC_HIP(hipFuncSetAttribute((const void*)als_finalize_kernel<NT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
         attr_done = true;
     }
     if (counts[0] > 0) {
-        hipLaunchKernelGGL(als_gram_cg_kernel<NT>, dim3((unsigned)counts[0]), dim3(64 * NT), S::BYTES, stream, indptr,
-                           indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row, cg_steps, partials);
+        // byte offsets into the gathered table are kept in 32 bits while the whole table is addressable that way
+        const bool big = y_rows <= 0 || (uint64_t)y_rows * (uint64_t)(S::F * 4) > (1ull << 32);
+        if (big)
+            hipLaunchKernelGGL((als_gram_cg_kernel<NT, true>), dim3((unsigned)counts[0]), dim3(64 * NT), S::BYTES,
+                               stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
+                               cg_steps, partials);
+        else
+            hipLaunchKernelGGL((als_gram_cg_kernel<NT, false>), dim3((unsigned)counts[0]), dim3(64 * NT), S::BYTES,
+                               stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
+                               cg_steps, partials);
         MIREC_LAUNCH_CHECK();
     }
     if (counts[1] > 0) {
@@ -750,12 +806,12 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     }
     if (host_counts[0] == 0 && host_counts[1] == 0) return MIREC_OK;
     switch (f / 32) {
-        case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
-        case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
-        case 3: return launch_sweep<3>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
-        case 4: return launch_sweep<4>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
-        case 5: return launch_sweep<5>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
-        case 6: return launch_sweep<6>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, stream);
+        case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
+        case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
+        case 3: return launch_sweep<3>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
+        case 4: return launch_sweep<4>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
+        case 5: return launch_sweep<5>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
+        case 6: return launch_sweep<6>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
     }
     return MIREC_E_UNSUPPORTED;
 }
