@@ -375,35 +375,30 @@ __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, Wa
     }
 }
 
-// Everything a wave does for one chunk once its wave index is a compile-time constant.  BIG: the gathered
-// table spans 4 GiB or more, so rows are addressed by 64-bit arithmetic instead of 32-bit byte offsets.
-template <int NT, int W, bool BIG>
-__device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indices, const float* __restrict__ data,
-                                                const float* __restrict__ Y, const float* __restrict__ G, int64_t ks,
-                                                int64_t ke, float* smem, bool single, float* P, int tid, int lane) {
+// The workgroup of a chunk has 2*NT waves in two roles that meet at one barrier per tile:
+//   producers (NT waves)  gather tile t+1, split it into the bf16 planes and store it into LDS buffer (t+1)&1,
+//   consumers (NT waves)  run the MFMAs of tile t from buffer t&1,
+// so that conversion and matrix-core work of consecutive tiles overlap on every SIMD.
+//
+// Producer thread p: columns 2*c2, 2*c2+1 of the eight entries 8*eg .. 8*eg+7 of a tile (a column's eight
+// entries make one 16-byte LDS chunk).  Gathered rows and confidences are requested one tile before they are
+// converted, indices two tiles before; each register set is overwritten only after its consumer ran.  Entries
+// past the end of the chunk repeat its last index and get confidence -1: weight 0 and no contribution to b.
+// BIG: the gathered table spans 4 GiB or more, so rows are addressed by 64-bit arithmetic instead of 32-bit
+// byte offsets.
+template <int NT, bool BIG>
+__device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indices, const float* __restrict__ data,
+                                              const float* __restrict__ Y, int64_t ks, int64_t ke, float* smem,
+                                              int ptid) {
     using C = GramCfg<NT>;
-    using WA = WaveAcc<NT, W>;
     constexpr int F = C::F;
-    float* big = smem;
     char* tiles = reinterpret_cast<char*>(smem);
     uint32_t* smask = reinterpret_cast<uint32_t*>(smem + C::SMASK);
     float* bred = smem + C::BRED;
-    float* bvec = smem + C::BVEC;
 
-    WA A;
-#pragma unroll
-    for (int j = 0; j < WA::N0; ++j) A.a0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < WA::N1; ++j) A.a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Staging of this thread: columns 2*c2, 2*c2+1 of the eight entries 8*eg .. 8*eg+7 of a tile (so that a
-    // column's eight entries make one 16-byte LDS chunk).  Gathered rows and confidences are loaded one tile
-    // ahead, indices two tiles ahead; each set is overwritten only after its consumer ran, so one register set
-    // of each suffices.  Entries past the end of the chunk repeat its last index and get confidence -1:
-    // weight 0 and no contribution to b.
     const int ntiles = (int)((ke - ks + TR - 1) / TR);
-    const int c2 = tid % (F / 2);
-    const int eg = tid / (F / 2);
+    const int c2 = ptid % (F / 2);
+    const int eg = ptid / (F / 2);
     int idx[8];
     float dd[8];
     f32x2 yv[8];
@@ -454,7 +449,9 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
         ++tile_d;
     };
     const int wbase = c2 * 128 + ((eg ^ (c2 & 3)) << 4);
-    auto store_tile = [&](char* tile, uint32_t* sm) __attribute__((always_inline)) {
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        char* tile = tiles + buf * C::TILE_BYTES;
+        uint32_t* sm = smask + buf * 16;
         float sw[8], w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -501,20 +498,46 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
     load_idx();
     load_rows();
     if (ntiles > 1) load_idx();
+    store_tile(0);
+    if (ntiles > 1) load_rows();
+    if (ntiles > 2) load_idx();
+    __syncthreads();  // tile 0 is in LDS
     for (int tile = 0; tile < ntiles; ++tile) {
-        char* tl = tiles + (tile & 1) * C::TILE_BYTES;
-        uint32_t* sm = smask + (tile & 1) * 16;
-        store_tile(tl, sm);
-        __syncthreads();
-        // gathers and confidences of the next tile (its indices arrived a tile ago), then the indices of the one after
-        if (tile + 1 < ntiles) load_rows();
-        if (tile + 2 < ntiles) load_idx();
-        __builtin_amdgcn_sched_barrier(0);
-        gram_tile<NT, W>(tl, sm, A, lane);
+        if (tile + 1 < ntiles) {
+            store_tile((tile + 1) & 1);
+            if (tile + 2 < ntiles) load_rows();
+            if (tile + 3 < ntiles) load_idx();
+        }
+        __syncthreads();  // tile + 1 is in LDS; the consumers are done with tile
     }
     bred[eg * F + 2 * c2] = bacc0;
     bred[eg * F + 2 * c2 + 1] = bacc1;
-    __syncthreads();  // every wave is done with the gather tiles that alias `big`; the b partials are visible
+}
+
+// Consumer wave W: accumulates its tiles over the chunk, then stores them (executes the same barriers as the
+// producers).
+template <int NT, int W>
+__device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int ntiles, float* smem, bool single,
+                                              float* P, int lane) {
+    using C = GramCfg<NT>;
+    using WA = WaveAcc<NT, W>;
+    constexpr int F = C::F;
+    float* big = smem;
+    const char* tiles = reinterpret_cast<const char*>(smem);
+    const uint32_t* smask = reinterpret_cast<const uint32_t*>(smem + C::SMASK);
+
+    WA A;
+#pragma unroll
+    for (int j = 0; j < WA::N0; ++j) A.a0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < WA::N1; ++j) A.a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        gram_tile<NT, W>(tiles + (tile & 1) * C::TILE_BYTES, smask + (tile & 1) * 16, A, lane);
+        __syncthreads();
+    }
+    // every consumer is past its last tile, so the tile buffers that alias `big` are free
 
     const int q = lane >> 4, i = lane & 15;
     if (single) {
@@ -537,7 +560,6 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
                 big[rr * F + cc] = v + G[rr * F + cc];
                 if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
             }
-        if (tid < F) bvec[tid] = (bred[tid] + bred[F + tid]) + (bred[2 * F + tid] + bred[3 * F + tid]);
     } else {
         // upper tiles only, tile-major: slot[tile][row][col]
 #pragma unroll
@@ -548,8 +570,6 @@ __device__ __forceinline__ void gram_chunk_wave(const int32_t* __restrict__ indi
         for (int j = 0; j < WA::N1; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) P[(C::row_start(WA::R1) + j) * 256 + (q * 4 + e) * 16 + i] = A.a1[j][e];
-        if (tid < F)
-            P[C::NTILES * 256 + tid] = (bred[tid] + bred[F + tid]) + (bred[2 * F + tid] + bred[3 * F + tid]);
     }
 }
 
@@ -560,15 +580,17 @@ __device__ __forceinline__ int64_t chunk_len(int64_t n, int nch) {
 }
 
 template <int NT, bool BIG>
-__global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
+__global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G,
     const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ mslot_ptr,
     const int32_t* __restrict__ chunk_row, int cg_steps, float* partials) {
     using C = GramCfg<NT>;
     constexpr int F = C::F;
+    constexpr int NTHR = 128 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* big = smem;
+    float* bred = smem + C::BRED;
     float* bvec = smem + C::BVEC;
     float* vec = smem + C::VEC;
 
@@ -585,7 +607,7 @@ __global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
     const int64_t rs = indptr[row], re = indptr[row + 1];
     float* xrow = X + row * F;
     if (rs == re) {
-        for (int i = tid; i < F; i += C::NTHR) xrow[i] = 0.f;
+        for (int i = tid; i < F; i += NTHR) xrow[i] = 0.f;
         return;
     }
     const int64_t clen = chunk_len(re - rs, nch);
@@ -595,17 +617,25 @@ __global__ __launch_bounds__(64 * NT) void als_gram_cg_kernel(
     float* P = single ? nullptr : partials + (size_t)(mslot_ptr[r] + lc) * C::PART_STRIDE;
     if (ks >= ke) {
         // rounding the chunk length up can leave a trailing chunk empty: its slot must still read as zero
-        for (int i = tid; i < C::PART_STRIDE; i += C::NTHR) P[i] = 0.f;
+        for (int i = tid; i < C::PART_STRIDE; i += NTHR) P[i] = 0.f;
         return;
     }
+    const int ntiles = (int)((ke - ks + TR - 1) / TR);
 
     switch (w) {
-        case 0: gram_chunk_wave<NT, 0, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 1: if constexpr (NT > 1) gram_chunk_wave<NT, 1, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 2: if constexpr (NT > 2) gram_chunk_wave<NT, 2, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 3: if constexpr (NT > 3) gram_chunk_wave<NT, 3, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 4: if constexpr (NT > 4) gram_chunk_wave<NT, 4, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
-        case 5: if constexpr (NT > 5) gram_chunk_wave<NT, 5, BIG>(indices, data, Y, G, ks, ke, smem, single, P, tid, lane); break;
+        case 0: gram_consumer<NT, 0>(G, ntiles, smem, single, P, lane); break;
+        case 1: if constexpr (NT > 1) gram_consumer<NT, 1>(G, ntiles, smem, single, P, lane); break;
+        case 2: if constexpr (NT > 2) gram_consumer<NT, 2>(G, ntiles, smem, single, P, lane); break;
+        case 3: if constexpr (NT > 3) gram_consumer<NT, 3>(G, ntiles, smem, single, P, lane); break;
+        case 4: if constexpr (NT > 4) gram_consumer<NT, 4>(G, ntiles, smem, single, P, lane); break;
+        case 5: if constexpr (NT > 5) gram_consumer<NT, 5>(G, ntiles, smem, single, P, lane); break;
+    }
+    if (w >= NT) gram_producer<NT, BIG>(indices, data, Y, ks, ke, smem, tid - 64 * NT);
+    __syncthreads();  // A (or the partial slot) and the b partials of the four entry groups are written
+    if (tid < F) {
+        const float b = (bred[tid] + bred[F + tid]) + (bred[2 * F + tid] + bred[3 * F + tid]);
+        if (single) bvec[tid] = b;
+        else P[C::NTILES * 256 + tid] = b;
     }
     if (single) {
         __syncthreads();
@@ -686,11 +716,11 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
         // byte offsets into the gathered table are kept in 32 bits while the whole table is addressable that way
         const bool big = y_rows <= 0 || (uint64_t)y_rows * (uint64_t)(S::F * 4) > (1ull << 32);
         if (big)
-            hipLaunchKernelGGL((als_gram_cg_kernel<NT, true>), dim3((unsigned)counts[0]), dim3(64 * NT), S::BYTES,
+            hipLaunchKernelGGL((als_gram_cg_kernel<NT, true>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
                                cg_steps, partials);
         else
-            hipLaunchKernelGGL((als_gram_cg_kernel<NT, false>), dim3((unsigned)counts[0]), dim3(64 * NT), S::BYTES,
+            hipLaunchKernelGGL((als_gram_cg_kernel<NT, false>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
                                cg_steps, partials);
         MIREC_LAUNCH_CHECK();
