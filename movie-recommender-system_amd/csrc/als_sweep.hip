@@ -162,86 +162,124 @@ static int exclusive_scan(int32_t* data, int64_t n, int32_t* scratch, hipStream_
     return MIREC_OK;
 }
 
-// out = A v for the symmetric LDS matrix A; lane holds columns lane + 64*m.
-template <int F>
-__device__ __forceinline__ void symv_wave(const float* A, float* vec, const float (&v)[(F + 63) / 64],
-                                          float (&out)[(F + 63) / 64], int lane) {
+// Conjugate-gradient steps of implicit's solver on the explicit system (A, b), run by all NW waves of the
+// workgroup (every thread must call it).  Wave 0 owns the CG state (lane holds columns lane + 64*m); each
+// product A v is split over the waves by k range, the partial vectors meet in LDS (`part`: NW*F + 4 floats)
+// and wave 0 sums them in wave order, so the result does not depend on timing.  x is read from and written
+// back to global memory.
+template <int F, int NW>
+__device__ void cg_solve_block(const float* A, const float* b, float* vec, float* part, float* xg, int cg_steps,
+                               int tid) {
     constexpr int NC = (F + 63) / 64;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int m = 0; m < NC; ++m) {
-        const int col = lane + 64 * m;
-        if (col < F) vec[col] = v[m];
-        out[m] = 0.f;
-    }
-    __builtin_amdgcn_wave_barrier();
+    constexpr int KW = F / NW;  // k range of one wave
+    static_assert(F % NW == 0 && KW % 4 == 0, "k ranges must be whole float4 groups");
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int* ctrl = reinterpret_cast<int*>(part + NW * F);
     int colc[NC];
 #pragma unroll
     for (int m = 0; m < NC; ++m) colc[m] = (lane + 64 * m < F) ? lane + 64 * m : F - 1;
-#pragma unroll 2
-    for (int k = 0; k < F; k += 4) {
-        const float4 pk = *reinterpret_cast<const float4*>(vec + k);
-#pragma unroll
-        for (int m = 0; m < NC; ++m) {
-            out[m] = fmaf(A[(k + 0) * F + colc[m]], pk.x, out[m]);
-            out[m] = fmaf(A[(k + 1) * F + colc[m]], pk.y, out[m]);
-            out[m] = fmaf(A[(k + 2) * F + colc[m]], pk.z, out[m]);
-            out[m] = fmaf(A[(k + 3) * F + colc[m]], pk.w, out[m]);
-        }
-    }
-}
 
-// Conjugate-gradient steps of implicit's solver on the explicit system (A, b),
-// run by one wavefront; x is read from and written back to global memory.
-template <int F>
-__device__ void cg_solve_wave(const float* A, const float* b, float* vec, float* xg, int cg_steps, int lane) {
-    constexpr int NC = (F + 63) / 64;
+    // out = A v (valid in wave 0); returns false in every wave when wave 0 passed go == false
+    auto symv_all = [&](const float (&v)[NC], float (&out)[NC], bool go) __attribute__((always_inline)) {
+        if (w == 0) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m)
+                if (lane + 64 * m < F) vec[lane + 64 * m] = v[m];
+            if (lane == 0) *ctrl = go ? 1 : 0;
+        }
+        __syncthreads();
+        if (*ctrl == 0) return false;
+        float o[NC];
+#pragma unroll
+        for (int m = 0; m < NC; ++m) o[m] = 0.f;
+#pragma unroll
+        for (int k = w * KW; k < w * KW + KW; k += 4) {
+            const float4 pk = *reinterpret_cast<const float4*>(vec + k);
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                o[m] = fmaf(A[(k + 0) * F + colc[m]], pk.x, o[m]);
+                o[m] = fmaf(A[(k + 1) * F + colc[m]], pk.y, o[m]);
+                o[m] = fmaf(A[(k + 2) * F + colc[m]], pk.z, o[m]);
+                o[m] = fmaf(A[(k + 3) * F + colc[m]], pk.w, o[m]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
+            if (lane + 64 * m < F) part[w * F + lane + 64 * m] = o[m];
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                float s = part[colc[m]];
+#pragma unroll
+                for (int ww = 1; ww < NW; ++ww) s += part[ww * F + colc[m]];
+                out[m] = s;
+            }
+        }
+        return true;
+    };
+
     float x[NC], r[NC], p[NC], Ap[NC];
 #pragma unroll
     for (int m = 0; m < NC; ++m) {
         const int col = lane + 64 * m;
-        x[m] = col < F ? xg[col] : 0.f;
+        x[m] = (w == 0 && col < F) ? xg[col] : 0.f;
+        Ap[m] = 0.f;
     }
-    symv_wave<F>(A, vec, x, Ap, lane);
-    float part = 0.f;
+    symv_all(x, Ap, true);
+    float partial = 0.f;
 #pragma unroll
     for (int m = 0; m < NC; ++m) {
         const int col = lane + 64 * m;
         r[m] = col < F ? b[col] - Ap[m] : 0.f;
         p[m] = r[m];
-        part = fmaf(r[m], r[m], part);
+        partial = fmaf(r[m], r[m], partial);
     }
-    float rsold = wave_sum(part);
-    if (rsold < 1e-20f) return;
+    float rsold = wave_sum(partial);
+    bool alive = !(rsold < 1e-20f);
     for (int it = 0; it < cg_steps; ++it) {
-        symv_wave<F>(A, vec, p, Ap, lane);
-        part = 0.f;
+        if (!symv_all(p, Ap, alive)) break;
+        partial = 0.f;
 #pragma unroll
         for (int m = 0; m < NC; ++m) {
             if (lane + 64 * m >= F) Ap[m] = 0.f;
-            part = fmaf(p[m], Ap[m], part);
+            partial = fmaf(p[m], Ap[m], partial);
         }
-        const float alpha = rsold / wave_sum(part);
-        part = 0.f;
+        const float alpha = rsold / wave_sum(partial);
+        partial = 0.f;
 #pragma unroll
         for (int m = 0; m < NC; ++m) {
             x[m] = fmaf(alpha, p[m], x[m]);
             r[m] = fmaf(-alpha, Ap[m], r[m]);
-            part = fmaf(r[m], r[m], part);
+            partial = fmaf(r[m], r[m], partial);
         }
-        const float rsnew = wave_sum(part);
-        if (rsnew < 1e-20f) break;
+        const float rsnew = wave_sum(partial);
+        alive = !(rsnew < 1e-20f);
         const float beta = rsnew / rsold;
 #pragma unroll
         for (int m = 0; m < NC; ++m) p[m] = fmaf(beta, p[m], r[m]);
         rsold = rsnew;
     }
+    if (w == 0) {
 #pragma unroll
-    for (int m = 0; m < NC; ++m) {
-        const int col = lane + 64 * m;
-        if (col < F) xg[col] = x[m];
+        for (int m = 0; m < NC; ++m) {
+            const int col = lane + 64 * m;
+            if (col < F) xg[col] = x[m];
+        }
     }
 }
+
+// Optional in-kernel phase timing (-DMIREC_DEBUG_TIMING): per-wave cycle counts summed into mirec_dbg and
+// read back with mirec_debug_read; tools/probes/gram_phase_timing.py prints them.
+#ifdef MIREC_DEBUG_TIMING
+__device__ unsigned long long mirec_dbg[16];
+#define DBG_T() __builtin_readcyclecounter()
+#define DBG_ADD(i, v) atomicAdd(&mirec_dbg[i], (unsigned long long)(v))
+#else
+#define DBG_T() 0ull
+#define DBG_ADD(i, v) do { } while (0)
+#endif
 
 // ------------------------------------------------------------- kernels -----
 // Geometry of the explicit-Gram kernel at width F = 32*NT:
@@ -271,12 +309,13 @@ struct GramCfg {
     static constexpr int BIGN = (F * F > 2 * TILE_FLOATS) ? F * F : 2 * TILE_FLOATS;
     static constexpr int PART_STRIDE = NTILES * 256 + F;  // floats of one partial-result slot
     // LDS map (floats): [0, BIGN) gather tiles / A; sign masks of the two tiles; b partials of the four entry
-    // groups; b; the CG work vector
+    // groups; b; the CG work vector; the CG partial products
     static constexpr int SMASK = BIGN;
     static constexpr int BRED = SMASK + 2 * 16;
     static constexpr int BVEC = BRED + 4 * F;
     static constexpr int VEC = BVEC + F;
-    static constexpr int FLOATS = VEC + F;
+    static constexpr int CGP = VEC + F;  // partial products of the block CG: one vector per wave + a control word
+    static constexpr int FLOATS = CGP + 2 * NT * F + 4;
     static constexpr size_t BYTES = (size_t)FLOATS * 4;
     // first tile id of band-row b in the row-major enumeration of the upper triangle
     static constexpr int row_start(int b) { return b * NB - b * (b - 1) / 2; }
@@ -381,9 +420,12 @@ __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, Wa
 // so that conversion and matrix-core work of consecutive tiles overlap on every SIMD.
 //
 // Producer thread p: columns 2*c2, 2*c2+1 of the eight entries 8*eg .. 8*eg+7 of a tile (a column's eight
-// entries make one 16-byte LDS chunk).  Gathered rows and confidences are requested one tile before they are
-// converted, indices two tiles before; each register set is overwritten only after its consumer ran.  Entries
-// past the end of the chunk repeat its last index and get confidence -1: weight 0 and no contribution to b.
+// entries make one 16-byte LDS chunk).  While tile t+1 is converted, the gathers of tiles t+2 and t+3 and the
+// indices of tile t+4 are in flight (two register sets each).  Indices are requested before the gathers of
+// the tile ahead of them, so that waiting for them (the memory counter retires in order) leaves those gathers
+// outstanding.  The steady-state loop is free of branches, which lets every wait name the exact number of
+// younger loads it may leave in flight.  Entries past the end of the chunk repeat its last index and get
+// confidence -1: weight 0 and no contribution to b.
 // BIG: the gathered table spans 4 GiB or more, so rows are addressed by 64-bit arithmetic instead of 32-bit
 // byte offsets.
 template <int NT, bool BIG>
@@ -397,20 +439,20 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
     float* bred = smem + C::BRED;
 
     const int ntiles = (int)((ke - ks + TR - 1) / TR);
+    const int nent = (int)(ke - ks);
     const int c2 = ptid % (F / 2);
     const int eg = ptid / (F / 2);
-    int idx[8];
-    float dd[8];
-    f32x2 yv[8];
+    int idx2[2][8];
+    float dd2[2][8];
+    f32x2 yv2[2][8];
     float bacc0 = 0.f, bacc1 = 0.f;
     const int32_t* ip = indices + ks + 8 * eg;
     const float* dp = data + ks + 8 * eg;
-    const int nent = (int)(ke - ks);
     int left_i = nent - 8 * eg;  // entries of the chunk from ip on (may be <= 0 in the last tile)
     int left_d = left_i;
-    int tile_i = 0, tile_d = 0;  // tiles whose indices / rows have been requested (wave-uniform)
-    auto load_idx = [&]() __attribute__((always_inline)) {
-        if ((tile_i + 1) * TR <= nent) {  // whole tile inside the chunk (uniform)
+    // `full`: the tile lies wholly inside the chunk (wave-uniform)
+    auto load_idx = [&](int (&idx)[8], bool full) __attribute__((always_inline)) {
+        if (full) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) idx[e] = ip[e];
         } else {
@@ -420,10 +462,10 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
         }
         ip += TR;
         left_i -= TR;
-        ++tile_i;
     };
     const uint32_t lane_off = (uint32_t)c2 * 8u;
-    auto load_rows = [&]() __attribute__((always_inline)) {
+    auto load_rows = [&](const int (&idx)[8], f32x2 (&yv)[8], float (&dd)[8], bool full)
+                         __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if constexpr (BIG) {
@@ -433,7 +475,7 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
                                                         ((uint32_t)idx[e] * (uint32_t)(F * 4) + lane_off));
             }
         }
-        if ((tile_d + 1) * TR <= nent) {
+        if (full) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dd[e] = dp[e];
         } else {
@@ -446,10 +488,10 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
         }
         dp += TR;
         left_d -= TR;
-        ++tile_d;
     };
     const int wbase = c2 * 128 + ((eg ^ (c2 & 3)) << 4);
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    unsigned long long dbg_a = 0, dbg_s[5] = {0, 0, 0, 0, 0};
+    auto store_tile = [&](const f32x2 (&yv)[8], const float (&dd)[8], int buf) __attribute__((always_inline)) {
         char* tile = tiles + buf * C::TILE_BYTES;
         uint32_t* sm = smask + buf * 16;
         float sw[8], w[8];
@@ -465,6 +507,7 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
         }
         // b is final for this tile before the next gathers overwrite yv
         asm volatile("" : "+v"(bacc0), "+v"(bacc1));
+        dbg_a = DBG_T();
         u32x4 hi[2], mid[2], lo[2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -494,24 +537,61 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
             *reinterpret_cast<u32x4*>(sm + 4 * eg) = sgn;
         }
     };
+    auto is_full = [&](int tile) __attribute__((always_inline)) { return (tile + 1) * TR <= nent; };
 
-    load_idx();
-    load_rows();
-    if (ntiles > 1) load_idx();
-    store_tile(0);
-    if (ntiles > 1) load_rows();
-    if (ntiles > 2) load_idx();
-    __syncthreads();  // tile 0 is in LDS
-    for (int tile = 0; tile < ntiles; ++tile) {
-        if (tile + 1 < ntiles) {
-            store_tile((tile + 1) & 1);
-            if (tile + 2 < ntiles) load_rows();
-            if (tile + 3 < ntiles) load_idx();
+    // Before phase t: tile t is in LDS buffer t & 1; the rows of tiles t+1 and t+2 are requested into register
+    // sets (t+1) & 1 and t & 1; the indices of tile t+3 are requested into index set (t+1) & 1.
+    auto phase = [&](auto set, auto steady, int tile) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+        constexpr bool STEADY = decltype(steady)::value;
+        const unsigned long long t0 = DBG_T();
+        unsigned long long t1 = t0, t2 = t0;
+        if (STEADY || tile + 1 < ntiles) {
+            store_tile(yv2[S ^ 1], dd2[S ^ 1], S ^ 1);
+            t1 = DBG_T();
+            if (STEADY || tile + 4 < ntiles) load_idx(idx2[S], STEADY || is_full(tile + 4));
+            if (STEADY || tile + 3 < ntiles) load_rows(idx2[S ^ 1], yv2[S ^ 1], dd2[S ^ 1], STEADY || is_full(tile + 3));
+            t2 = DBG_T();
         }
         __syncthreads();  // tile + 1 is in LDS; the consumers are done with tile
+#ifdef MIREC_DEBUG_TIMING
+        if (STEADY) {
+            const unsigned long long t3 = DBG_T();
+            dbg_s[0] += dbg_a - t0;  // wait for rows + weights + b
+            dbg_s[1] += t1 - dbg_a;  // split + LDS stores
+            dbg_s[2] += t2 - t1;     // issue of the next loads
+            dbg_s[3] += t3 - t2;     // barrier
+            dbg_s[4] += 1;
+        }
+#endif
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+
+    load_idx(idx2[0], is_full(0));
+    if (ntiles > 1) load_idx(idx2[1], is_full(1));
+    load_rows(idx2[0], yv2[0], dd2[0], is_full(0));
+    if (ntiles > 2) load_idx(idx2[0], is_full(2));
+    if (ntiles > 1) load_rows(idx2[1], yv2[1], dd2[1], is_full(1));
+    if (ntiles > 3) load_idx(idx2[1], is_full(3));
+    store_tile(yv2[0], dd2[0], 0);
+    if (ntiles > 2) load_rows(idx2[0], yv2[0], dd2[0], is_full(2));
+    __syncthreads();  // tile 0 is in LDS
+    int tile = 0;
+    for (; tile + 6 < ntiles; tile += 2) {  // every tile touched below is a full one that exists
+        phase(T0{}, std::true_type{}, tile);
+        phase(T1{}, std::true_type{}, tile + 1);
+    }
+    for (; tile < ntiles; ++tile) {
+        if (tile & 1) phase(T1{}, std::false_type{}, tile);
+        else phase(T0{}, std::false_type{}, tile);
     }
     bred[eg * F + 2 * c2] = bacc0;
     bred[eg * F + 2 * c2 + 1] = bacc1;
+#ifdef MIREC_DEBUG_TIMING
+    if (ptid == 0)
+        for (int i = 0; i < 5; ++i) DBG_ADD(i, dbg_s[i]);
+#endif
 }
 
 // Consumer wave W: accumulates its tiles over the chunk, then stores them (executes the same barriers as the
@@ -533,10 +613,22 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
     for (int j = 0; j < WA::N1; ++j) A.a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();
+    unsigned long long dbg_w = 0, dbg_b = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
+        const unsigned long long t0 = DBG_T();
         gram_tile<NT, W>(tiles + (tile & 1) * C::TILE_BYTES, smask + (tile & 1) * 16, A, lane);
+        const unsigned long long t1 = DBG_T();
         __syncthreads();
+        dbg_w += t1 - t0;
+        dbg_b += DBG_T() - t1;
     }
+#ifdef MIREC_DEBUG_TIMING
+    if (W == 0 && lane == 0) {
+        DBG_ADD(8, dbg_w);
+        DBG_ADD(9, dbg_b);
+        DBG_ADD(10, ntiles);
+    }
+#endif
     // every consumer is past its last tile, so the tile buffers that alias `big` are free
 
     const int q = lane >> 4, i = lane & 15;
@@ -597,6 +689,7 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    const unsigned long long dbg_k0 = DBG_T();
 
     const int chunk = blockIdx.x;
     const int r = chunk_row[chunk];
@@ -632,6 +725,7 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     }
     if (w >= NT) gram_producer<NT, BIG>(indices, data, Y, ks, ke, smem, tid - 64 * NT);
     __syncthreads();  // A (or the partial slot) and the b partials of the four entry groups are written
+    const unsigned long long dbg_k1 = DBG_T();
     if (tid < F) {
         const float b = (bred[tid] + bred[F + tid]) + (bred[2 * F + tid] + bred[3 * F + tid]);
         if (single) bvec[tid] = b;
@@ -639,8 +733,15 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     }
     if (single) {
         __syncthreads();
-        if (w == 0) cg_solve_wave<F>(big, bvec, vec, xrow, cg_steps, lane);
+        cg_solve_block<F, 2 * NT>(big, bvec, vec, smem + C::CGP, xrow, cg_steps, tid);
     }
+#ifdef MIREC_DEBUG_TIMING
+    if (tid == 0) {
+        DBG_ADD(12, dbg_k1 - dbg_k0);    // whole chunk up to the stored A / partial
+        DBG_ADD(13, DBG_T() - dbg_k1);   // b sum + CG
+        DBG_ADD(14, 1);
+    }
+#endif
 }
 
 // Split rows: sum the chunk partials in chunk order, add G, mirror the upper triangle, solve.
@@ -689,7 +790,7 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
         }
     }
     __syncthreads();
-    if (tid < 64) cg_solve_wave<F>(big, bvec, vec, X + (row_begin + r) * F, cg_steps, tid);
+    cg_solve_block<F, NT>(big, bvec, vec, smem + C::CGP, X + (row_begin + r) * F, cg_steps, tid);
 }
 
 template <int NT>
@@ -736,6 +837,17 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
 }  // namespace mirec
 
 using namespace mirec;
+
+#ifdef MIREC_DEBUG_TIMING
+extern "C" int mirec_debug_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mirec_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mirec_dbg), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif
 
 extern "C" size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk_nnz) {
     if (nrows < 0 || nnz < 0) return 0;

@@ -1,0 +1,27 @@
+"""Phase timing of the explicit-Gram kernel (library built with -DMIREC_DEBUG_TIMING)."""
+import ctypes, sys, os, torch
+sys.path.insert(0, "/root/repo")
+from movie_recommender_system_amd import engine as E, synth, _lib
+dev = torch.device("cuda", 0)
+U, I, F = 1_000_000, 27_000, 128
+indptr, indices, data = synth.interactions_torch(42, U, I, 50.0, dev)
+Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
+g = torch.Generator(device=dev); g.manual_seed(1)
+X = torch.rand((U, F), device=dev, generator=g) * 0.1
+Y = torch.rand((I, F), device=dev, generator=g) * 0.1
+csr = Cui.transpose()
+G = E.gram(X, 0.01)
+plan = E.SweepPlan(csr, F)
+lib = _lib.require()
+out = (ctypes.c_ulonglong * 16)()
+plan.sweep(Y, X, G, 3); torch.cuda.synchronize()
+lib.mirec_debug_read(out, 1)
+plan.sweep(Y, X, G, 3); torch.cuda.synchronize()
+lib.mirec_debug_read(out, 1)
+v = list(out)
+n = max(v[4], 1)
+print("producer (steady phases, %d): wait+weights %.0f  split+store %.0f  load issue %.0f  barrier %.0f cycles" %
+      (v[4], v[0] / n, v[1] / n, v[2] / n, v[3] / n))
+print("consumer: work %.0f  barrier %.0f  cycles/tile over %d tiles" % (v[8] / max(v[10], 1), v[9] / max(v[10], 1), v[10]))
+print("per chunk (%d): gather+Gram+store %.0f  b+CG %.0f cycles" % (v[14], v[12] / max(v[14], 1), v[13] / max(v[14], 1)))
+print("tiles per chunk %.1f" % (v[10] / max(v[14], 1)))
