@@ -1,82 +1,150 @@
 // Shared Gram matrix  G = Y^T Y + reg*I  on the fp32 matrix cores.
 //
 // Row blocks of Y are contracted with v_mfma_f32_32x32x2_f32 (an exact fp32
-// fma chain over the rows), one 32-row band of G per wavefront; block partials
-// are then summed in a fixed order (fp64 accumulation, one rounding), so the
-// result does not depend on scheduling.
+// fma chain over the rows).  Only the 32x32 tiles on or above the diagonal are
+// formed: a wave owns band-rows w and NT-1-w (NT+1 tiles), two groups of such
+// waves split the rows of a workgroup, and the loads of the next eight rows are
+// in flight while the current ones are multiplied.  Block partials are then
+// summed in a fixed order (fp64 accumulation, one rounding) and mirrored, so
+// the result is symmetric to the bit and does not depend on scheduling.
 #include "common.h"
 
 namespace mirec {
 
-// Rows handled by one workgroup: at most ~1024 workgroups, at least 256 rows.
+constexpr int GRAM_GROUPS = 2;  // wave groups per workgroup, each with its own partial slot
+
+// Rows handled by one workgroup: at most ~512 workgroups, at least 512 rows.
 static inline int gram_rows_per_block(int64_t n) {
-    int64_t r = (n + 1023) / 1024;
-    if (r < 256) r = 256;
-    r = (r + 7) / 8 * 8;
+    int64_t r = (n + 511) / 512;
+    if (r < 512) r = 512;
+    r = (r + 15) / 16 * 16;
     return (int)r;
 }
 
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void gram_partial_kernel(const float* __restrict__ Y, int64_t n,
-                                                               int rows_per_block,
-                                                               float* __restrict__ partials) {
+struct GramWaves {
+    static constexpr int ROLES = (NT + 1) / 2;  // waves per group
+    static constexpr int NW = ROLES * GRAM_GROUPS;
+};
+
+// Wave role W of a group: band-rows W and R1 = NT-1-W (the same one when NT is odd and W is the middle).
+template <int NT, int W>
+__device__ __forceinline__ void gram_rows_wave(const float* __restrict__ Y, int64_t r0, int64_t r1, float* out,
+                                               int lane) {
     constexpr int F = 32 * NT;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // band of G rows
-    const int lane = threadIdx.x & 63;
+    constexpr int R1 = NT - 1 - W;
+    constexpr int N0 = NT - W;                  // tiles (W, W..NT-1)
+    constexpr int N1 = (R1 > W) ? (W + 1) : 0;  // tiles (R1, R1..NT-1)
     const int h = lane >> 5;  // which of the two rows of a k-step this lane feeds
     const int c = lane & 31;
 
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
-
-    f32x16 acc[NT];
+    f32x16 acc0[N0];
+    f32x16 acc1[N1 > 0 ? N1 : 1];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < N0; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc0[t][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < N1; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[t][i] = 0.f;
 
-    for (int64_t r = r0; r < r1; r += 8) {
-        float a[4];
-        float b[4][NT];
+    // b[p][t]: column 32*(W+t) + c of row r + 2p + h; rows past the end read row r0 and are zeroed
+    float cur[4][N0], nxt[4][N0];
+    auto load = [&](float (&b)[4][N0], int64_t r) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int64_t row = r + 2 * p + h;
             const bool valid = row < r1;
-            const float* yr = Y + (valid ? row : r0) * F;
-            const float av = yr[w * 32 + c];
-            a[p] = valid ? av : 0.f;
+            const float* yr = Y + (valid ? row : r0) * F + W * 32 + c;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float bv = yr[t * 32 + c];
-                b[p][t] = valid ? bv : 0.f;
+            for (int t = 0; t < N0; ++t) {
+                const float v = yr[t * 32];
+                b[p][t] = valid ? v : 0.f;
             }
+        }
+    };
+    if (r0 < r1) load(cur, r0);
+    for (int64_t r = r0; r < r1; r += 8) {
+        if (r + 8 < r1) load(nxt, r + 8);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int t = 0; t < N0; ++t)
+                acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[p][0], cur[p][t], acc0[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < N1; ++t)
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[p][R1 - W], cur[p][R1 - W + t], acc1[t], 0, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[p][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < N0; ++t) cur[p][t] = nxt[p][t];
     }
 
-    float* out = partials + (size_t)blockIdx.x * F * F;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < N0; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            out[(size_t)(w * 32 + row) * F + t * 32 + c] = acc[t][i];
+            out[(size_t)(W * 32 + row) * F + (W + t) * 32 + c] = acc0[t][i];
+        }
+#pragma unroll
+    for (int t = 0; t < N1; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            out[(size_t)(R1 * 32 + row) * F + (R1 + t) * 32 + c] = acc1[t][i];
         }
 }
 
-__global__ void gram_reduce_kernel(const float* __restrict__ partials, int nblk, int f, float reg,
-                                   float* __restrict__ G) {
+// Partial slot (blockIdx, group): F x F floats of which only the tiles on or above the diagonal are written.
+template <int NT>
+__global__ __launch_bounds__(64 * GramWaves<NT>::NW) void gram_partial_kernel(const float* __restrict__ Y, int64_t n,
+                                                                              int rows_per_block,
+                                                                              float* __restrict__ partials) {
+    constexpr int F = 32 * NT;
+    constexpr int ROLES = GramWaves<NT>::ROLES;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int group = w / ROLES, role = w % ROLES;
+    const int half = rows_per_block / GRAM_GROUPS;  // a multiple of 8
+
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block + (int64_t)group * half;
+    int64_t r1 = r0 + half;
+    if (r0 > n) r0 = n;
+    if (r1 > n) r1 = n;
+    float* out = partials + ((size_t)blockIdx.x * GRAM_GROUPS + group) * F * F;
+    switch (role) {
+        case 0: gram_rows_wave<NT, 0>(Y, r0, r1, out, lane); break;
+        case 1: if constexpr (ROLES > 1) gram_rows_wave<NT, 1>(Y, r0, r1, out, lane); break;
+        case 2: if constexpr (ROLES > 2) gram_rows_wave<NT, 2>(Y, r0, r1, out, lane); break;
+    }
+}
+
+// One workgroup per 64 elements of the upper block triangle; four threads share the slots of an element
+// (slot s goes to thread s & 3) and their fp64 sums are combined in a fixed order.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ partials, int nslots, int f,
+                                                          float reg, float* __restrict__ G) {
+    __shared__ double part[4][64];
     const int ff = f * f;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ff) return;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q = threadIdx.x >> 6;
+    const int i = e / f, j = e % f;
+    const bool upper = e < ff && (i >> 5) <= (j >> 5);
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * ff + e];
-    if (e / f == e % f) s += (double)reg;
-    G[e] = (float)s;
+    if (upper)
+        for (int b = q; b < nslots; b += 4) s += (double)partials[(size_t)b * ff + e];
+    part[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && upper) {
+        const int t = threadIdx.x;
+        double tot = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+        if (i == j) tot += (double)reg;
+        const float g = (float)tot;
+        G[e] = g;
+        if ((i >> 5) < (j >> 5)) G[j * f + i] = g;
+    }
 }
 
 template <int NT>
@@ -85,11 +153,12 @@ static int launch_gram(const float* Y, int64_t n, float reg, float* G, float* pa
     const int rpb = gram_rows_per_block(n);
     const int nblk = (int)((n + rpb - 1) / rpb);
     if (nblk > 0) {
-        hipLaunchKernelGGL(gram_partial_kernel<NT>, dim3(nblk), dim3(64 * NT), 0, stream, Y, n, rpb, partials);
+        hipLaunchKernelGGL(gram_partial_kernel<NT>, dim3(nblk), dim3(64 * GramWaves<NT>::NW), 0, stream, Y, n, rpb,
+                           partials);
         MIREC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((F * F + 255) / 256), dim3(256), 0, stream, partials, nblk, F, reg,
-                       G);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((F * F + 63) / 64), dim3(256), 0, stream, partials,
+                       nblk * GRAM_GROUPS, F, reg, G);
     MIREC_LAUNCH_CHECK();
     return MIREC_OK;
 }
@@ -100,7 +169,7 @@ extern "C" size_t mirec_gram_workspace_bytes(int64_t n, int f) {
     if (n < 0 || f <= 0) return 0;
     const int rpb = mirec::gram_rows_per_block(n);
     const int64_t nblk = (n + rpb - 1) / rpb;
-    return (size_t)(nblk > 0 ? nblk : 1) * f * f * sizeof(float);
+    return (size_t)(nblk > 0 ? nblk : 1) * mirec::GRAM_GROUPS * f * f * sizeof(float);
 }
 
 extern "C" int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, size_t ws_bytes,
