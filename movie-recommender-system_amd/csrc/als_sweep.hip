@@ -762,18 +762,26 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
     const int r = multi_row[blockIdx.x];
     const int nch = chunk_ptr[r + 1] - chunk_ptr[r];
     const float* P = partials + (size_t)mslot_ptr[r] * C::PART_STRIDE;
-    for (int e = tid; e < C::PART_STRIDE; e += C::NTHR) {
-        float s = 0.f;
-        int ch = 0;
-        for (; ch + 4 <= nch; ch += 4) {
-            const float p0 = P[(size_t)(ch + 0) * C::PART_STRIDE + e];
-            const float p1 = P[(size_t)(ch + 1) * C::PART_STRIDE + e];
-            const float p2 = P[(size_t)(ch + 2) * C::PART_STRIDE + e];
-            const float p3 = P[(size_t)(ch + 3) * C::PART_STRIDE + e];
-            s = ((s + p0) + p1) + p2;
-            s += p3;
+    // every thread sums its elements tid, tid + NTHR, ... over the chunks in chunk order; the loads of one chunk
+    // (one per element) are independent, so a whole slot row is in flight per thread
+    constexpr int NE = (C::PART_STRIDE + C::NTHR - 1) / C::NTHR;
+    float acc[NE];
+#pragma unroll
+    for (int it = 0; it < NE; ++it) acc[it] = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* Pc = P + (size_t)ch * C::PART_STRIDE;
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            const int e = tid + it * C::NTHR;
+            const float v = Pc[e < C::PART_STRIDE ? e : C::PART_STRIDE - 1];
+            acc[it] += e < C::PART_STRIDE ? v : 0.f;
         }
-        for (; ch < nch; ++ch) s += P[(size_t)ch * C::PART_STRIDE + e];
+    }
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+        const int e = tid + it * C::NTHR;
+        if (e >= C::PART_STRIDE) continue;
+        const float s = acc[it];
         if (e >= C::NTILES * 256) {
             bvec[e - C::NTILES * 256] = s;
         } else {
