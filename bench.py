@@ -198,6 +198,7 @@ def main():
             e = d.get(tag, {}).get("mirec::" + kernel, {})
             if "hbm_bytes_per_launch" in e:
                 return e["hbm_bytes_per_launch"]
+            break  # the newest capture of this workload has no such kernel: nothing older applies
         return None
 
     entries = [(tag, k, b, ms, n) for tag, csr, plan in (("user", eng.Cui_local, eng.plan_u), ("item", eng.Ciu_local, eng.plan_i))
@@ -205,9 +206,12 @@ def main():
     rl_all = []
     for tag, k, b, ms, n in entries:
         gbs = (b / (ms * 1e-3) / 1e9) if (b and ms > 0) else None
-        rl_all.append({"side": tag, "kernel": f"{k}<{F // 32}>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+        # second template argument: 64-bit addressing of the gathered table (4 GiB and more)
+        wide = "true" if (I if tag == "user" else U) * F * 4 > (1 << 32) else "false"
+        kname = f"{k}<{F // 32}, {wide}>"
+        rl_all.append({"side": tag, "kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None,
-                       "traffic": pmc_traffic(tag, f"{k}<{F // 32}>"),
+                       "traffic": pmc_traffic(tag, kname),
                        "bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n})
     dom = max(rl_all, key=lambda e: e["avg_launch_ms"]) if rl_all else None
     roofline = dict(dom) if dom else None
