@@ -140,6 +140,7 @@ def main():
     X = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, F, dev)
     Y = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, F, dev)
     drv, eng = D.gpu_driver(Cui, Ciu, X, Y, args.regularization, 3, rank, world)
+    X = drv.X  # the driver's padded copy is the user factor matrix from here on
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
@@ -160,24 +161,25 @@ def main():
         elapsed = float(t.item())
     s_per_iter = elapsed / args.steps
 
-    # ---- roofline: one entry per half-sweep kernel (live HIP-event time per launch, algorithmic bytes of
-    # the rows that kernel solved); the dominant one (more time per iteration) is reported as `roofline`.
-    def side(tag, csr, plan):
-        rows, nz = csr.shape[0], csr.nnz
-        n_short = plan.n_short_rows
+    # ---- roofline: one entry per half-sweep kernel (live HIP-event time, algorithmic bytes of the rows that
+    # kernel solved); the dominant one (more time per iteration) is reported as `roofline`.  On one GPU a
+    # half-sweep is one launch of its kernel; on N GPUs the user side is cut into blocks (one launch each, the
+    # exchange of a block overlaps the next), and the figures are then per half-sweep: bytes of all of this
+    # rank's blocks over the summed duration of their launches.
+    u_rows, u_nnz, u_short, u_chunks = eng.user_totals()
+
+    def side(tag, rows, nz):
         out = []
         t_s, c_s = times.get(tag + "_short", (0.0, 0))
         t_m, c_m = times.get(tag + "_main", (0.0, 0))
-        # stored entries are attributed to the two kernels by their share of the rows' entries; at the
-        # benchmark shape one side is all matrix-free rows and the other all explicit-Gram rows
+        # at the benchmark shape one side is all matrix-free rows and the other all explicit-Gram rows
         if c_s and not c_m:
-            out.append(("als_short_kernel", sweep_bytes(nz, rows, F), t_s / c_s, c_s))
+            out.append(("als_short_kernel", sweep_bytes(nz, rows, F), t_s / args.steps, c_s))
         elif c_m and not c_s:
-            out.append(("als_gram_cg_kernel", sweep_bytes(nz, rows, F), t_m / c_m, c_m))
+            out.append(("als_gram_cg_kernel", sweep_bytes(nz, rows, F), t_m / args.steps, c_m))
         elif c_m and c_s:
-            frac = n_short / max(rows, 1)
-            out.append(("als_short_kernel", None, t_s / c_s, c_s))
-            out.append(("als_gram_cg_kernel", None, t_m / c_m, c_m))
+            out.append(("als_short_kernel", None, t_s / args.steps, c_s))
+            out.append(("als_gram_cg_kernel", None, t_m / args.steps, c_m))
         return out
 
     # HBM-side bytes per launch cannot be read from inside this process: they come from separate
@@ -201,8 +203,9 @@ def main():
             break  # the newest capture of this workload has no such kernel: nothing older applies
         return None
 
-    entries = [(tag, k, b, ms, n) for tag, csr, plan in (("user", eng.Cui_local, eng.plan_u), ("item", eng.Ciu_local, eng.plan_i))
-               for (k, b, ms, n) in side(tag, csr, plan)]
+    entries = [(tag, k, b, ms, n) for tag, rows, nz in (("user", u_rows, u_nnz),
+                                                        ("item", eng.Ciu_local.shape[0], eng.Ciu_local.nnz))
+               for (k, b, ms, n) in side(tag, rows, nz)]
     rl_all = []
     for tag, k, b, ms, n in entries:
         gbs = (b / (ms * 1e-3) / 1e9) if (b and ms > 0) else None
@@ -213,43 +216,52 @@ def main():
                        "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None,
                        "traffic": pmc_traffic(tag, kname),
                        "bytes_per_launch": b, "avg_launch_ms": ms, "launches_timed": n})
+        # (per half-sweep of this rank; equal to per launch when the side is one block, as on one GPU)
     dom = max(rl_all, key=lambda e: e["avg_launch_ms"]) if rl_all else None
     roofline = dict(dom) if dom else None
     kernel_ms = {k: v[0] / max(v[1], 1) for k, v in times.items()}
 
     extra = {"setup_s": t_setup, "nnz": nnz, "kernel_ms_per_launch": kernel_ms, "half_sweep_rooflines": rl_all,
-             "iteration_GBps": (sweep_bytes(eng.Cui_local.nnz, eng.Cui_local.shape[0], F) +
+             "iteration_GBps": (sweep_bytes(u_nnz, u_rows, F) +
                                 sweep_bytes(eng.Ciu_local.nnz, eng.Ciu_local.shape[0], F)) / s_per_iter / 1e9,
-             "user_short_rows": eng.plan_u.n_short_rows, "item_short_rows": eng.plan_i.n_short_rows,
-             "user_chunks": eng.plan_u.n_chunks, "item_chunks": eng.plan_i.n_chunks,
+             "user_short_rows": u_short, "item_short_rows": eng.plan_i.n_short_rows,
+             "user_chunks": u_chunks, "item_chunks": eng.plan_i.n_chunks,
+             "user_blocks": len(eng.user_blocks),
              "item_split_rows": eng.plan_i.n_split_rows}
 
-    # ---- top-K pass for this rank's users (no exchange needed)
+    # ---- top-K pass for this rank's users (no exchange needed): one launch per owned block of users
     if not args.no_topk:
-        u0, u1 = drv.user_bounds[rank], drv.user_bounds[rank + 1]
         W = E.factor_width(f, for_scoring=True)
-        Q = X[u0:u1] if W == F else X[u0:u1, :W].contiguous()
         Ys = Y if W == F else Y[:, :W].contiguous()
-        mask = E.DeviceCSR(indptr, indices, data, (U, I)).row_slice(u0, u1)
-        E.topk(Q[:4096], Ys, args.topk, mask.row_slice(0, min(4096, u1 - u0)))
+        full_mask = E.DeviceCSR(indptr, indices, data, (U, I))
+        jobs = []
+        for u0, u1 in drv.user_blocks:
+            if u1 > u0:
+                Q = X[u0:u1] if W == F else X[u0:u1, :W].contiguous()
+                jobs.append((Q, full_mask.row_slice(u0, u1)))
+        n_local = sum(q.shape[0] for q, _ in jobs)
+        if jobs:
+            q0, m0 = jobs[0]
+            nw = min(4096, q0.shape[0])
+            E.topk(q0[:nw], Ys, args.topk, m0.row_slice(0, nw))
         barrier()
         t0 = time.perf_counter()
         reps = 2
         for _ in range(reps):
-            ids, scores = E.topk(Q, Ys, args.topk, mask)
+            outs = [E.topk(Q, Ys, args.topk, m) for Q, m in jobs]
         barrier()
         tk = (time.perf_counter() - t0) / reps
         if world > 1:
             t = torch.tensor([tk], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tk = float(t.item())
-        flops = 2.0 * (u1 - u0) * I * W
+        flops = 2.0 * n_local * I * W
         extra["top20_users_per_s"] = U / tk
         extra["top20_pass_ms"] = tk * 1e3
         extra["topk_roofline"] = {"kernel": "topk_kernel<%d,%s>" % (W, "4,56" if args.topk <= 24 else "4,128" if args.topk <= 96 else "2,256"), "bound": "mfma",
                                   "achieved": flops / tk / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": flops / tk / 1e12 / MFMA_F32_PEAK_TFLOPS}
-        del ids, scores
+        del outs
 
     # ---- LightFM hybrid scoring (configs[4]): segment-sum + dot + top-20 for all users, rank 0's share
     if not args.no_lightfm and rank == 0:
@@ -281,7 +293,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"implicit ALS (CG-3) f={f} fp32, {U} users x {I} movies, {nnz} interactions, "
                                    f"alpha={args.alpha:g}, reg={args.regularization:g}; then top-{args.topk} for all users",
-                       "users": U, "items": I, "nnz": nnz, "factors": f, "sharding": f"rows-by-nnz x{world}"},
+                       "users": U, "items": I, "nnz": nnz, "factors": f, "sharding": f"users block-cyclic, items by stored entries, x{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out), flush=True)

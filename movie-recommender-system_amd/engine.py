@@ -15,7 +15,7 @@ call.  Classes:
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import scipy.sparse as sp
@@ -194,12 +194,14 @@ class SweepPlan:
 class AlsEngine:
     """All device state of one ALS fit on one GPU.
 
-    ``user_rows`` / ``item_rows`` restrict the rows this engine solves (the
-    shard of one rank); the factor matrices are always held whole.
+    ``user_blocks`` (row ranges, solved in order) / ``item_rows`` restrict the
+    rows this engine solves (the shard of one rank); the factor matrices are
+    always held whole.
     """
 
     def __init__(self, Cui: DeviceCSR, Ciu: Optional[DeviceCSR], X: torch.Tensor, Y: torch.Tensor,
-                 regularization: float, cg_steps: int = 3, user_rows: Optional[Tuple[int, int]] = None,
+                 regularization: float, cg_steps: int = 3,
+                 user_blocks: Optional[Sequence[Tuple[int, int]]] = None,
                  item_rows: Optional[Tuple[int, int]] = None, chunk_nnz: int = 0, short_max: Optional[int] = None):
         self.f = int(X.shape[1])
         assert Y.shape[1] == self.f
@@ -208,12 +210,14 @@ class AlsEngine:
         users, items = Cui.shape
         if Ciu is None:
             Ciu = Cui.transpose()
-        self.user_rows = user_rows or (0, users)
+        self.user_blocks = [tuple(b) for b in (user_blocks if user_blocks is not None else [(0, users)])]
         self.item_rows = item_rows or (0, items)
-        cu = Cui if self.user_rows == (0, users) else Cui.row_slice(*self.user_rows)
+        self.plans_u = []
+        for a, b in self.user_blocks:
+            cu = Cui if (a, b) == (0, users) else Cui.row_slice(a, b)
+            self.plans_u.append(SweepPlan(cu, self.f, chunk_nnz, short_max) if b > a else None)
         ci = Ciu if self.item_rows == (0, items) else Ciu.row_slice(*self.item_rows)
-        self.Cui_local, self.Ciu_local = cu, ci
-        self.plan_u = SweepPlan(cu, self.f, chunk_nnz, short_max)
+        self.Ciu_local = ci
         self.plan_i = SweepPlan(ci, self.f, chunk_nnz, short_max)
         lib = _lib.require()
         need = max(lib.mirec_gram_workspace_bytes(users, self.f), lib.mirec_gram_workspace_bytes(items, self.f))
@@ -245,10 +249,30 @@ class AlsEngine:
         if plan.n_split_rows:
             self._run(tag + "_finalize", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "finalize"))
 
+    @property
+    def plan_u(self) -> "SweepPlan":
+        """The user-side plan of an engine with a single user block."""
+        assert len(self.plans_u) == 1
+        return self.plans_u[0]
+
+    def user_totals(self) -> Tuple[int, int, int, int]:
+        """(rows, stored entries, rows of the matrix-free kernel, chunks) over this engine's user blocks."""
+        ps = [p for p in self.plans_u if p is not None]
+        return (sum(p.csr.shape[0] for p in ps), sum(p.csr.nnz for p in ps), sum(p.n_short_rows for p in ps),
+                sum(p.n_chunks for p in ps))
+
+    def user_sweep_block(self, j: int) -> None:
+        """Solve user block j; block 0 first refreshes the Gram of Y."""
+        if j == 0:
+            self._run("gram_items", lambda: gram(self.Y, self.reg, self.G, self.gram_ws))
+        plan = self.plans_u[j]
+        if plan is not None:
+            u0, u1 = self.user_blocks[j]
+            self._sweep("user", plan, self.X[u0:u1], self.Y)
+
     def user_sweep(self) -> None:
-        self._run("gram_items", lambda: gram(self.Y, self.reg, self.G, self.gram_ws))
-        u0, u1 = self.user_rows
-        self._sweep("user", self.plan_u, self.X[u0:u1], self.Y)
+        for j in range(len(self.user_blocks)):
+            self.user_sweep_block(j)
 
     def item_sweep(self) -> None:
         self._run("gram_users", lambda: gram(self.X, self.reg, self.G, self.gram_ws))

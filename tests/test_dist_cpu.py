@@ -38,6 +38,26 @@ def test_partition_rows_balances_entries():
     assert D.partition_rows(np.array([100, 110, 120, 130, 140], dtype=np.int64), 2) == [0, 2, 4]
 
 
+def test_block_cyclic_ownership():
+    u = D.BlockCyclic(1000, 4, blocks=3)
+    assert u.padded >= 1000 and u.padded == u.bs * 12 and u.bs % 16 == 0
+    seen = np.zeros(u.padded, dtype=np.int32)
+    for r in range(4):
+        owned = u.owned(r)
+        assert len(owned) == 3
+        for j, (a, b) in enumerate(owned):
+            pa, pb = u.block(j, r)
+            s0, s1 = u.slab(j)
+            assert s0 <= pa < pb <= s1 and pb - pa == u.bs
+            assert (a, b) == (min(pa, 1000), min(pb, 1000))
+            seen[pa:pb] += 1
+    assert np.all(seen == 1)                       # every padded row has exactly one owner
+    one = D.BlockCyclic(10, 1)
+    assert one.owned(0) == [(0, 10)] and one.padded >= 10
+    tiny = D.BlockCyclic(5, 8, blocks=2)           # more blocks than rows: empty ranges are allowed
+    assert sum(b - a for r in range(8) for a, b in tiny.owned(r)) == 5
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -56,18 +76,20 @@ def _worker(rank, world, port, out_dir):
         Cui = sp.csr_matrix(M * np.float32(40.0))
         Ciu = sp.csr_matrix(Cui.T)
         X0, Y0 = oracle.oracle.init_factors(300, 90, 16, 42)
-        X, Y = torch.from_numpy(X0.copy()), torch.from_numpy(Y0.copy())
-        Xn, Yn = X.numpy(), Y.numpy()   # views: the oracle updates the tensors in place
-        ub = D.partition_rows(Cui.indptr, world)
+        users = D.BlockCyclic(300, world, blocks=3)
+        Xpad = torch.zeros((users.padded, 16), dtype=torch.float32)
+        Xpad[:300] = torch.from_numpy(X0)
+        Y = torch.from_numpy(Y0.copy())
+        Xn, Yn = Xpad[:300].numpy(), Y.numpy()   # views: the oracle updates the tensors in place
         ib = D.partition_rows(Ciu.indptr, world)
         drv = D.ShardedAlsDriver(
-            X, Y, ub, ib,
+            Xpad, Y, users, ib,
             lambda a, b: oracle.als_half_sweep(Cui, Xn, Yn, 0.01, 3, rows=(a, b)),
             lambda a, b: oracle.als_half_sweep(Ciu, Yn, Xn, 0.01, 3, rows=(a, b)),
             rank)
         for _ in range(3):
             drv.iteration()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), X=Xn, Y=Yn, ub=np.array(ub), ib=np.array(ib))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), X=Xn, Y=Yn, ub=np.array(drv.user_blocks), ib=np.array(ib))
     finally:
         dist.destroy_process_group()
 
@@ -81,7 +103,7 @@ def test_two_ranks_equal_single_process(tmp_path):
     Xr, Yr = oracle.als_fit(M, factors=16, regularization=0.01, alpha=40.0, iterations=3, random_state=42)
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
-    assert 0 < r0["ub"][1] < 300 and 0 < r0["ib"][1] < 90
+    assert r0["ub"].shape == (3, 2) and not np.array_equal(r0["ub"], r1["ub"]) and 0 < r0["ib"][1] < 90
     for r in (r0, r1):
         assert np.array_equal(r["X"], Xr)
         assert np.array_equal(r["Y"], Yr)
