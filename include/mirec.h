@@ -99,6 +99,20 @@ int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const fl
                          const int64_t host_counts[4], void* ws, size_t ws_bytes, mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Interaction-matrix build (`build_matrix`, als/als.py:107-123, after the ids
+ * have been mapped to indices on the host): duplicate (user, item) events
+ * collapse to one stored entry of value 1.0 (the groupby at :118 and the ones at
+ * :121); rows come out with ascending column indices.  `indices` / `data` must
+ * hold n_events entries; the number of unique pairs is written to the device
+ * scalar `nnz_out`, and `item_counts` (optional, n_items ints) receives the
+ * number of users per item -- the column sums behind `most_popular_movies`
+ * (als/als.py:175-176, recommenders/als_recommender.py:138-139). */
+size_t mirec_events_to_csr_workspace_bytes(int64_t n_events, int64_t n_users);
+int mirec_events_to_csr(const int32_t* user_idx, const int32_t* item_idx, int64_t n_events, int64_t n_users,
+                        int64_t n_items, int64_t* indptr, int32_t* indices, float* data, int32_t* item_counts,
+                        int64_t* nnz_out, void* ws, size_t ws_bytes, mirec_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * CSR transpose (`Ciu = Cui.T.tocsr()` inside implicit's fit; same call
  * sites).  Output rows keep ascending column order.  `ws` must hold
  * mirec_csr_transpose_workspace_bytes(rows, cols, nnz) bytes. */
@@ -143,6 +157,17 @@ int mirec_lightfm_repr(const int64_t* indptr, const int32_t* indices, const floa
  * urepr/irepr are [*, nc+1] with the bias in column nc. */
 int mirec_lightfm_predict(const float* urepr, const float* irepr, const int32_t* user_ids,
                           const int32_t* item_ids, int64_t n, int nc, float* out, mirec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Held-out ranking evaluation over the top-k output (the evaluation cell of
+ * notebooks/baseline_als.ipynb, cells 66ca94ea / fd92678d; LightFM's
+ * precision_at_k / recall_at_k as called at hybrid_docker/utils.py:111-155).
+ * rec_ids is [n_users, k] (negative = no recommendation), the held-out matrix a
+ * CSR with ascending column indices per row.  Per user: hits = |set(recs) n
+ * held-out|, n_rec = recommendations that are not negative.  The averages are
+ * formed by the caller from these counts. */
+int mirec_ranking_hits(const int32_t* rec_ids, int64_t n_users, int k, const int64_t* held_indptr,
+                       const int32_t* held_indices, int32_t* hits, int32_t* n_rec, mirec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,9 @@ SIGNATURES = {
     "mirec_topk": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "mirec_lightfm_repr": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _int, _vp, _int, _int, _int, _int, _vp]),
     "mirec_lightfm_predict": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _vp]),
+    "mirec_events_to_csr_workspace_bytes": (_sz, [_i64, _i64]),
+    "mirec_events_to_csr": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mirec_ranking_hits": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

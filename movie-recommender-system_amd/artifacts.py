@@ -44,6 +44,34 @@ def build_matrix(user_ids: Iterable, movie_ids: Iterable) -> Tuple[sp.csr_matrix
     return matrix, user_to_idx, movie_to_idx, idx_to_movie
 
 
+def build_matrix_device(user_ids: Iterable, movie_ids: Iterable, device=None):
+    """``build_matrix`` with the grouping done on the GPU.  The id handling stays
+    on the host because its contract is about strings (ids compared as ``str``,
+    indexed in lexicographic order, ``als/als.py:109-115``); the events are then
+    shipped as two int32 index arrays and deduplicated, sorted and counted by
+    ``mirec_events_to_csr``.  Returns (DeviceCSR, user_to_idx, movie_to_idx,
+    idx_to_movie, item_counts) where item_counts is the int32 device tensor of
+    users per item (the column sums the popularity order is built from)."""
+    import torch
+
+    from .engine import DeviceCSR
+
+    u = np.asarray([str(x) for x in user_ids], dtype=object)
+    m = np.asarray([str(x) for x in movie_ids], dtype=object)
+    if len(u) != len(m):
+        raise ValueError("user_ids and movie_ids differ in length")
+    users, rows = np.unique(u.astype(str), return_inverse=True) if len(u) else (np.array([], dtype=str), np.array([], dtype=np.int64))
+    movies, cols = np.unique(m.astype(str), return_inverse=True) if len(m) else (np.array([], dtype=str), np.array([], dtype=np.int64))
+    user_to_idx = {str(k): i for i, k in enumerate(users.tolist())}
+    movie_to_idx = {str(k): i for i, k in enumerate(movies.tolist())}
+    idx_to_movie = {i: k for k, i in movie_to_idx.items()}
+    dev = torch.device(device) if device is not None else torch.device("cuda")
+    du = torch.from_numpy(rows.astype(np.int32)).to(dev)
+    dm = torch.from_numpy(cols.astype(np.int32)).to(dev)
+    csr, counts = DeviceCSR.from_events(du, dm, (len(users), len(movies)), with_item_counts=True)
+    return csr, user_to_idx, movie_to_idx, idx_to_movie, counts
+
+
 def popularity_order(matrix: sp.spmatrix, convention: str = "sort_then_reverse") -> np.ndarray:
     """Item indices by descending interaction count (column sums of the
     unscaled matrix).  The reference has two conventions that differ on ties:

@@ -78,6 +78,31 @@ class DeviceCSR:
             data = data * np.float32(scale)
         return cls(indptr, indices, torch.from_numpy(data).to(device), m.shape)
 
+    @classmethod
+    def from_events(cls, user_idx: torch.Tensor, item_idx: torch.Tensor, shape: Tuple[int, int],
+                    with_item_counts: bool = False):
+        """Binary CSR of the unique (user, item) pairs of an event list (int32
+        device tensors): duplicates collapse, every stored value is 1.0, rows
+        have ascending columns.  With ``with_item_counts`` also returns the
+        number of users per item (int32 tensor)."""
+        lib = _lib.require()
+        assert user_idx.dtype == torch.int32 and item_idx.dtype == torch.int32
+        assert user_idx.is_contiguous() and item_idx.is_contiguous() and user_idx.numel() == item_idx.numel()
+        dev = user_idx.device
+        n, (nu, ni) = int(user_idx.numel()), shape
+        indptr = torch.empty(nu + 1, dtype=torch.int64, device=dev)
+        indices = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        data = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        counts = torch.empty(max(ni, 1), dtype=torch.int32, device=dev) if with_item_counts else None
+        nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(max(int(lib.mirec_events_to_csr_workspace_bytes(n, nu)), 1), dtype=torch.uint8, device=dev)
+        _lib.check(lib.mirec_events_to_csr(_ptr(user_idx), _ptr(item_idx), n, nu, ni, _ptr(indptr), _ptr(indices),
+                                           _ptr(data), _ptr(counts), _ptr(nnz), _ptr(ws), ws.numel(), _stream_ptr()),
+                   "mirec_events_to_csr")
+        k = int(nnz.item())
+        csr = cls(indptr, indices[:k].clone(), data[:k].clone(), (nu, ni))
+        return (csr, counts[:ni]) if with_item_counts else csr
+
     def transpose(self) -> "DeviceCSR":
         """``.T.tocsr()`` on the device (stable sort by column)."""
         lib = _lib.require()

@@ -1,0 +1,84 @@
+"""Held-out ranking metrics from the device hit counts equal the CPU evaluation
+(oracle/als_numpy.py: the metric definition of the reference's notebook) bit for
+bit: the counts are integers and the averages are accumulated in the same order."""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import als_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("nu,ni,k,dens", [(1, 5, 3, 0.5), (257, 90, 20, 0.05), (1000, 400, 10, 0.01), (64, 30, 20, 0.0)])
+def test_ranking_metrics_match_cpu(dev, nu, ni, k, dens):
+    from movie_recommender_system_amd import evaluate
+    rng = np.random.default_rng(nu * 7 + k)
+    held = sp.random(nu, ni, density=dens, format="csr", random_state=nu, dtype=np.float32)
+    held.sort_indices()
+    rec = rng.integers(0, ni, size=(nu, k)).astype(np.int32)     # duplicates inside a row are possible
+    rec[rng.random((nu, k)) < 0.1] = -1                           # "no recommendation" slots
+    if nu > 10:
+        rec[3] = -1                                               # a user without any recommendation
+    ref = als_numpy.ranking_metrics(rec, held, k)
+    got = evaluate.ranking_metrics(rec, held, k, device=dev)
+    for key in ("precision", "recall", "f1", "hit_rate", "users"):
+        assert got[key] == ref[key], (key, got[key], ref[key])
+    assert got["recall_at_k"] == ref["recall"]
+
+
+def test_hits_after_a_fit(dev):
+    """End to end: fit, top-20, device evaluation == CPU evaluation of the same ids."""
+    from movie_recommender_system_amd import AlternatingLeastSquares, evaluate, synth
+    M = synth.interactions(11, 800, 200, 15.0)
+    train, test = synth.split_holdout(M, 1, 0.2)
+    model = AlternatingLeastSquares(factors=32, iterations=3, alpha=40.0, random_state=42)
+    model.fit(train)
+    ids, _ = model.recommend_all(train, N=20)
+    ref = als_numpy.ranking_metrics(ids, test, 20)
+    got = evaluate.ranking_metrics(ids, test, 20, device=dev)
+    assert {k: got[k] for k in ref} == ref
+    assert 0.0 < got["hit_rate"] <= 1.0 and got["precision_at_k"] <= got["precision"] + 1e-12
+
+
+@pytest.mark.parametrize("n_events,nu,ni", [(0, 3, 4), (1, 1, 1), (5000, 300, 80), (200000, 20000, 700)])
+def test_events_to_csr_matches_host_build(dev, n_events, nu, ni):
+    """Duplicate events collapse, rows are sorted, values are ones, item counts are the column sums
+    (als/als.py:107-123,175-176) -- the same arrays as scipy builds on the host."""
+    import torch
+    from movie_recommender_system_amd import engine as E
+    rng = np.random.default_rng(n_events + nu)
+    u = rng.integers(0, nu, size=n_events).astype(np.int32)
+    m = (rng.zipf(1.5, size=n_events) % ni).astype(np.int32)
+    csr, counts = E.DeviceCSR.from_events(torch.from_numpy(u).to(dev), torch.from_numpy(m).to(dev), (nu, ni),
+                                          with_item_counts=True)
+    got = csr.to_scipy()
+    ref = sp.csr_matrix((np.ones(n_events, dtype=np.float32), (u, m)), shape=(nu, ni))
+    ref.sum_duplicates()
+    ref.data[:] = 1.0
+    ref.sort_indices()
+    assert got.shape == ref.shape and got.nnz == ref.nnz
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    assert got.data.dtype == np.float32 and np.all(got.data == 1.0)
+    assert np.array_equal(counts.cpu().numpy(), np.asarray(ref.sum(axis=0)).ravel().astype(np.int32))
+
+
+def test_build_matrix_device_keeps_the_string_order_contract(dev):
+    from movie_recommender_system_amd import artifacts
+    users = [10, 9, 10, "a", 9, 10, 2, "10"]
+    movies = ["m2", "m1", "m2", "m1", "m10", "m1", "m2", "m10"]
+    M, u2i, m2i, i2m = artifacts.build_matrix(users, movies)
+    D, du2i, dm2i, di2m, counts = artifacts.build_matrix_device(users, movies, device=dev)
+    assert du2i == u2i and dm2i == m2i and di2m == i2m
+    got = D.to_scipy()
+    assert np.array_equal(got.toarray(), M.toarray()) and got.dtype == np.float32
+    assert np.array_equal(counts.cpu().numpy(), np.asarray(M.sum(axis=0)).ravel().astype(np.int32))
