@@ -134,10 +134,18 @@ int mirec_csr_transpose(const int64_t* indptr, const int32_t* indices, const flo
  * filter_already_liked_items=True), :237 (similar_items),
  * hybrid_docker/inference.py:197 (argsort top-k, via mirec_lightfm_*).
  * mask_indptr may be null (no filter); it is indexed by query row, and every
- * mask row must list its items in ascending order. */
+ * mask row must list its items in ascending order.
+ * ws (device memory, 256-byte aligned, ws_bytes >= mirec_topk_workspace_bytes)
+ * is optional scratch: with it, plain scoring (no norms) at f in {64, 96, 128}
+ * and k <= 24 runs the selection on bf16 matrix-core scores with an error
+ * margin and re-scores the survivors with the fp32 chain above, so the output
+ * is the same bit for bit and arrives about three times sooner.  ws may be
+ * null (or the size query 0): the fp32 kernel then does all the work.  The
+ * contents of ws mean nothing to the caller before or after the call. */
+size_t mirec_topk_workspace_bytes(int64_t nq, int64_t ni, int f, int k);
 int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, int f, const int64_t* mask_indptr,
                const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
-               float* out_scores, mirec_stream_t stream);
+               float* out_scores, void* ws, size_t ws_bytes, mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * LightFM representations (lightfm `compute_representation`, reached from

@@ -1,17 +1,24 @@
 // C entry point of the fused score + top-K; the kernel template lives in
 // topk_kernel.h and is instantiated per factor width in topk_inst_*.hip.
 #include "common.h"
+#include "topk_workspace.h"
 
 namespace mirec {
 template <int F>
 int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
                 const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
-                float* out_scores, hipStream_t stream);
+                float* out_scores, void* ws, size_t ws_bytes, hipStream_t stream);
 }  // namespace mirec
+
+extern "C" size_t mirec_topk_workspace_bytes(int64_t nq, int64_t ni, int f, int k) {
+    if (nq <= 0 || ni <= 0 || !mirec::topk_planes_supported(f, k)) return 0;
+    return mirec::topk_workspace_layout(nq, ni, f).bytes;
+}
 
 extern "C" int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, int f,
                           const int64_t* mask_indptr, const int32_t* mask_indices, const float* y_norm,
-                          const float* q_norm, int k, int32_t* out_ids, float* out_scores, mirec_stream_t stream_) {
+                          const float* q_norm, int k, int32_t* out_ids, float* out_scores, void* ws, size_t ws_bytes,
+                          mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MIREC_REQUIRE(nq >= 0 && ni >= 0, MIREC_E_INVALID, "mirec_topk: negative size");
     MIREC_REQUIRE(k >= 1, MIREC_E_INVALID, "mirec_topk: k must be >= 1 (got %d)", k);
@@ -24,7 +31,7 @@ extern "C" int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni
 #define MIREC_TOPK_CASE(FW)                                                                                    \
     case FW:                                                                                                   \
         return mirec::launch_topk<FW>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,    \
-                                      out_scores, stream);
+                                      out_scores, ws, ws_bytes, stream);
     switch (f) {
         MIREC_TOPK_CASE(8)
         MIREC_TOPK_CASE(16)

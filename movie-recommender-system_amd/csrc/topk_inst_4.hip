@@ -1,6 +1,6 @@
-#include "topk_kernel.h"
+#include "topk_planes_kernel.h"
 
 namespace mirec {
 template int launch_topk<160>(const float*, int64_t, const float*, int64_t, const int64_t*, const int32_t*,
-                              const float*, const float*, int, int32_t*, float*, hipStream_t);
+                              const float*, const float*, int, int32_t*, float*, void*, size_t, hipStream_t);
 }  // namespace mirec

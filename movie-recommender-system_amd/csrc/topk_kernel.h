@@ -89,7 +89,10 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     const float* __restrict__ Q, int64_t nq, const float* __restrict__ Y, int64_t ni,
     const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices,
     const float* __restrict__ y_norm, const float* __restrict__ q_norm, int k, int32_t* __restrict__ out_ids,
-    float* __restrict__ out_scores) {
+    float* __restrict__ out_scores, const int32_t* __restrict__ qlist, const int32_t* __restrict__ qcount) {
+    // List mode (qlist != nullptr): the workgroups process the *qcount queries whose indices are listed in
+    // qlist, in list order; everything per query (factor row, mask row, norm, output row) is addressed
+    // through the list.  The launch covers the worst case, surplus workgroups leave at once.
     using L = TopkLds<F, WAVES, CAP>;
     constexpr int KS = F / 2;
     constexpr int BI = TOPK_BI;
@@ -112,7 +115,14 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     float* tau = reinterpret_cast<float*>(cnt + 32);
     unsigned* lmask = reinterpret_cast<unsigned*>(tau + 32);  // [32]: liked bits of the current item tile
 
-    const int64_t u0 = (int64_t)blockIdx.x * (32 * WAVES) + w * 32;  // first query of this wave
+    const int64_t u0 = (int64_t)blockIdx.x * (32 * WAVES) + w * 32;  // first query (slot) of this wave
+    if (qlist != nullptr) {
+        nq = *qcount;
+        if ((int64_t)blockIdx.x * (32 * WAVES) >= nq) return;
+    }
+    auto query_of = [&](int64_t slot) __attribute__((always_inline)) {
+        return (qlist != nullptr && slot < nq) ? (int64_t)qlist[slot] : slot;
+    };
     if (lane < 32) {
         cnt[lane] = 0;
         tau[lane] = -INFINITY;
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     {
         const int64_t u = u0 + c;
         const bool uv = u < nq;
-        const float* qr = Q + (uv ? u : 0) * F + h;
+        const float* qr = Q + (uv ? query_of(u) : 0) * F + h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float v = qr[2 * s];
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
         const int64_t ug = u0 + (i & 3) + 8 * (i >> 2) + 4 * h;
         tau_r[i] = -INFINITY;
         urow_ok[i] = ug < nq;
-        qn_r[i] = (q_norm != nullptr && ug < nq) ? q_norm[ug] : 1.f;
+        qn_r[i] = (q_norm != nullptr && ug < nq) ? q_norm[query_of(ug)] : 1.f;
     }
 
     // Liked-item filter: lane u < 32 walks the (ascending) mask row of query u0 + u with a cursor, one
@@ -149,8 +159,9 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     int64_t cur = 0, cend = 0;
     int nxt = 0x7fffffff;
     if (mask_indptr != nullptr && lane < 32 && u0 + lane < nq) {
-        cur = mask_indptr[u0 + lane];
-        cend = mask_indptr[u0 + lane + 1];
+        const int64_t uq = query_of(u0 + lane);
+        cur = mask_indptr[uq];
+        cend = mask_indptr[uq + 1];
         if (cur < cend) nxt = mask_indices[cur];
     }
 
@@ -160,14 +171,15 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
     auto load_y = [&](f32x4 (&pre)[NV], int64_t i0) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int e = tid + v * NTHR;
+            // unconditional (a branch around a load makes the compiler wait for it on the spot): threads past
+            // the tile repeat its last element, rows past the last item repeat the last item (never candidates)
+            int e = tid + v * NTHR;
+            e = e < TILE_V4 ? e : TILE_V4 - 1;
             const int j = e / F4;
             const int k4 = e % F4;
-            const int64_t item = i0 + j;
-            if (e < TILE_V4 && item < ni)
-                pre[v] = *reinterpret_cast<const f32x4*>(Y + item * F + 4 * k4);
-            else
-                pre[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int64_t item = i0 + j;
+            item = item < ni ? item : ni - 1;
+            pre[v] = *reinterpret_cast<const f32x4*>(Y + (item > 0 ? item : 0) * F + 4 * k4);
         }
     };
     auto store_y = [&](const f32x4 (&pre)[NV]) __attribute__((always_inline)) {
@@ -294,8 +306,10 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
         }
     };
 
-    load_y(pre0, 0);
-    load_y(pre1, BI);
+    if (ni > 0) {
+        load_y(pre0, 0);
+        load_y(pre1, BI);
+    }
     for (int64_t i0 = 0; i0 < ni; i0 += 2 * BI) {
         __syncthreads();  // previous tile fully consumed
         store_y(pre0);
@@ -312,8 +326,8 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
 
     // ---- final compaction and output
     for (int ur = 0; ur < 32; ++ur) {
-        const int64_t ug = u0 + ur;
-        if (ug >= nq) break;
+        if (u0 + ur >= nq) break;
+        const int64_t ug = query_of(u0 + ur);
         compact_wave<CAP>(sel_s + ur * CAP, sel_i + ur * CAP, cnt + ur, tau + ur, k, lane);
         const int n = __builtin_amdgcn_readfirstlane(cnt[ur]);
         for (int j = lane; j < k; j += 64) {
@@ -326,7 +340,8 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
 template <int F, int WAVES, int CAP>
 static int launch_topk_cfg(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
                            const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k,
-                           int32_t* out_ids, float* out_scores, hipStream_t stream) {
+                           int32_t* out_ids, float* out_scores, const int32_t* qlist, const int32_t* qcount,
+                           hipStream_t stream) {
     using L = TopkLds<F, WAVES, CAP>;
     static bool attr_done = false;  // idempotent; a race only repeats the call
     if (!attr_done) {
@@ -336,24 +351,24 @@ static int launch_topk_cfg(const float* Q, int64_t nq, const float* Y, int64_t n
     }
     const int64_t blocks = (nq + 32 * WAVES - 1) / (32 * WAVES);
     hipLaunchKernelGGL((topk_kernel<F, WAVES, CAP>), dim3((unsigned)blocks), dim3(64 * WAVES), L::BYTES, stream, Q, nq,
-                       Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids, out_scores);
+                       Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids, out_scores, qlist, qcount);
     MIREC_LAUNCH_CHECK();
     return MIREC_OK;
 }
 
 // Buffer size by k: CAP - 32 >= k.  56 entries (k <= 24) lets two 4-wave workgroups share a CU.
 template <int F>
-int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
-                const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
-                float* out_scores, hipStream_t stream) {
+int launch_topk_fused(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
+                      const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
+                      float* out_scores, const int32_t* qlist, const int32_t* qcount, hipStream_t stream) {
     if (k <= 24)
         return launch_topk_cfg<F, 4, 56>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
-                                         out_scores, stream);
+                                         out_scores, qlist, qcount, stream);
     if (k <= 96)
         return launch_topk_cfg<F, 4, 128>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
-                                          out_scores, stream);
+                                          out_scores, qlist, qcount, stream);
     return launch_topk_cfg<F, 2, 256>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids,
-                                      out_scores, stream);
+                                      out_scores, qlist, qcount, stream);
 }
 
 }  // namespace mirec

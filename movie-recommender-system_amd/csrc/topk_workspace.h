@@ -1,0 +1,34 @@
+// Layout of the optional workspace of mirec_topk (host side only).
+//
+//   [0, 256)            header: u32 bits of max ||y|| at byte 0, i32 length of the query list at byte 4
+//   [256, 256 + Lq)     query list: int32 per query (Lq = 4*nq rounded up to 256)
+//   [.., .. + Lp)       item factors split into two bf16 planes (hi, mid), tile by tile:
+//                       [tile][plane][32 items][f] bf16, rows past the last item zero
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mirec {
+
+constexpr int TOPK_PLANE_KMAX = 24;  // largest k the bf16-plane kernel serves
+constexpr int TOPK_NPLANES = 2;      // bf16 planes per factor matrix
+
+inline bool topk_planes_supported(int f, int k) {
+    return (f == 64 || f == 96 || f == 128) && k >= 1 && k <= TOPK_PLANE_KMAX;
+}
+
+struct TopkWorkspace {
+    size_t qlist_off, planes_off, bytes;
+};
+
+inline TopkWorkspace topk_workspace_layout(int64_t nq, int64_t ni, int f) {
+    TopkWorkspace w;
+    w.qlist_off = 256;
+    const size_t lq = ((size_t)nq * 4 + 255) / 256 * 256;
+    w.planes_off = w.qlist_off + lq;
+    const size_t ntile = (size_t)((ni + 31) / 32);
+    w.bytes = w.planes_off + ntile * TOPK_NPLANES * 32 * (size_t)f * 2;
+    return w;
+}
+
+}  // namespace mirec

@@ -320,9 +320,12 @@ class AlsEngine:
 
 def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = None,
          y_norm: Optional[torch.Tensor] = None, q_norm: Optional[torch.Tensor] = None,
-         n_items: Optional[int] = None):
+         n_items: Optional[int] = None, workspace: bool = True):
     """Fused score + top-k of every row of Q against the first n_items rows of Y.
-    Returns device tensors (ids int32 [nq, k], scores fp32 [nq, k])."""
+    Returns device tensors (ids int32 [nq, k], scores fp32 [nq, k]).  With
+    ``workspace`` the library's scratch (for the bf16-plane kernel, where it
+    applies) is taken from torch's caching allocator; results are identical
+    either way."""
     lib = _lib.require()
     nq, f = Q.shape
     ni = int(Y.shape[0] if n_items is None else n_items)
@@ -331,7 +334,13 @@ def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = N
         assert mask.shape[0] == nq, "one mask row per query"
     ids = torch.empty((nq, k), dtype=torch.int32, device=Q.device)
     scores = torch.empty((nq, k), dtype=torch.float32, device=Q.device)
+    ws = None
+    ws_bytes = 0
+    if workspace and y_norm is None and q_norm is None:
+        ws_bytes = int(lib.mirec_topk_workspace_bytes(nq, ni, f, int(k)))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Q.device)
     _lib.check(lib.mirec_topk(_ptr(Q), nq, _ptr(Y), ni, f, _ptr(None if mask is None else mask.indptr),
                               _ptr(None if mask is None else mask.indices), _ptr(y_norm), _ptr(q_norm), int(k),
-                              _ptr(ids), _ptr(scores), _stream_ptr()), "mirec_topk")
+                              _ptr(ids), _ptr(scores), _ptr(ws), ws_bytes, _stream_ptr()), "mirec_topk")
     return ids, scores

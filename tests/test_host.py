@@ -38,9 +38,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_rejects_bad_arguments_without_touching_a_device():
     lib = _lib.load()
-    rc = lib.mirec_topk(None, 4, None, 4, 20, None, None, None, None, 0, None, None, None)
+    rc = lib.mirec_topk(None, 4, None, 4, 20, None, None, None, None, 0, None, None, None, 0, None)
     assert rc == -1 and "k must be" in _lib.last_error()
-    rc = lib.mirec_topk(None, 4, None, 4, 20, None, None, None, None, 500, None, None, None)
+    rc = lib.mirec_topk(None, 4, None, 4, 20, None, None, None, None, 500, None, None, None, 0, None)
     assert rc == -4 and "224" in _lib.last_error()
     rc = lib.mirec_gram(None, 10, 50, 0.1, None, None, 0, None)
     assert rc != 0
