@@ -26,10 +26,10 @@
 //
 // A workgroup owns 32*WM query rows.  Its WM "matrix" waves keep 32 queries each
 // as split MFMA A operands in registers, sweep the items in tiles of 32 and do
-// nothing but operand reads, 6*F/16 MFMAs and four 16-byte stores of the score
-// tile per item tile.  Two "selector" waves per matrix wave consume the score
-// tile of the previous item tile, stage the next tile of the pre-split planes
-// into LDS (double buffered) and own all selection state: thresholds and fill
+// nothing but plane staging, operand reads, 4*F/16 MFMAs and four 16-byte stores
+// of the score tile per item tile.  Two "selector" waves per matrix wave consume the score
+// tile of the previous item tile and own all selection state (the matrix waves
+// also stage the next tile of the pre-split planes into LDS, double buffered): thresholds and fill
 // counts in registers, candidates found with one ballot per query row (which
 // also assigns the slots -- no atomics), buffers compacted by a wave-wide
 // bit-serial k-th-best search (no sort) only when a tile's candidates would not
@@ -199,8 +199,8 @@ __device__ __forceinline__ int compact_margin(float* ss, int* ii, int n_in, int 
 }
 
 // Sweep-time compaction of one query's buffer (n <= CAP <= 64 entries, one per lane, n >= k): find the k-th
-// best score tau by a bit-serial search on an order-preserving integer image of the scores (one compare and
-// one population count per bit, no sort), then keep -- in place, in buffer order, which is ascending item
+// best score tau by a digit-serial search on an order-preserving integer image of the scores (three compares
+// and population counts per two bits, no sort), then keep -- in place, in buffer order, which is ascending item
 // order and stays so -- the entries that beat tau - marg; among entries equal to tau the earliest ones
 // complete the k when the margin does not cover them (zero margin).  At most `limit` entries are kept.
 // Returns the number kept; thr_out = the new entry threshold, over = the margin set did not fit.
@@ -215,12 +215,18 @@ __device__ __forceinline__ int compact_select(float* ss, int* ii, int n_in, int 
     const int iv = valid ? ii[lane] : 0;
     const uint32_t bits = __float_as_uint(sv);
     const uint32_t key = valid ? (bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u)) : 0u;
+    // two bits per step: the three trial values are independent compares, the chain is 16 steps long
+    auto count_ge = [&](uint32_t trial) __attribute__((always_inline)) {
+        return __builtin_popcountll(__builtin_amdgcn_uicmp(key, trial, 35 /* unsigned >= */));
+    };
     uint32_t prefix = 0u;
 #pragma unroll
-    for (int b = 31; b >= 0; --b) {
-        const uint32_t trial = prefix | (1u << b);
-        const int cge = __builtin_popcountll(__ballot(key >= trial));
-        prefix = cge >= k ? trial : prefix;
+    for (int b = 30; b >= 0; b -= 2) {
+        const int c1 = count_ge(prefix | (1u << b));
+        const int c2 = count_ge(prefix | (2u << b));
+        const int c3 = count_ge(prefix | (3u << b));
+        const uint32_t add = c3 >= k ? 3u : (c2 >= k ? 2u : (c1 >= k ? 1u : 0u));
+        prefix |= add << b;
     }
     const uint32_t tb = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
     const float tau = __uint_as_float(tb);
@@ -281,7 +287,7 @@ __device__ __forceinline__ int compact_sorted(float* ss, int* ii, int n_in, int 
 }
 
 constexpr int TOPK_PLANES_SEL = 2;      // selector waves per matrix wave
-constexpr int TOPK_EARLY_COMPACT = 12;  // new entries that make a buffer worth compacting in an idle tile
+constexpr int TOPK_EARLY_COMPACT = 8;   // entries beyond k that make a buffer worth compacting on the schedule
 
 template <int F, int WM, int CAP>
 struct TopkPlanesLds {
@@ -343,10 +349,47 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                 tk_split8(a, b, qh[s], qm[s]);
             }
         }
+        // Plane staging by the matrix waves (the selectors' time per tile varies, the matrix waves' does not):
+        // tile t + 2 is in registers during the MFMAs of tile t and goes to LDS at the start of tile t + 1.
+        constexpr int NTS = 64 * WM;
+        constexpr int TILE_CH = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile
+        constexpr int NV = (TILE_CH + NTS - 1) / NTS;
+        tk_u32x4 pre[NV];
+        // Unconditional loads (a branch around a load makes the compiler wait for it on the spot): threads past
+        // the tile repeat its last chunk.
+        auto load_y = [&](int t) __attribute__((always_inline)) {
+            const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_CH;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int e = tid + v * NTS;
+                e = e < TILE_CH ? e : TILE_CH - 1;
+                pre[v] = src[e];
+            }
+        };
+        auto store_y = [&](char* ytile) __attribute__((always_inline)) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int e = tid + v * NTS;
+                e = e < TILE_CH ? e : TILE_CH - 1;  // duplicates write the same values
+                const int row = e / F8;             // plane * 32 + item
+                const int kc = e % F8;
+                *reinterpret_cast<tk_u32x4*>(ytile + row * L::ROWB + 16 * kc) = pre[v];
+            }
+        };
+        if (ntile > 0) {
+            load_y(0);
+            store_y(ybuf);
+        }
+        load_y(ntile > 1 ? 1 : 0);
         __syncthreads();  // tile 0 is staged
         unsigned long long dm = 0, db = 0;
         for (int t = 0; t < ntile; ++t) {
             const unsigned long long t0 = TKS_T();
+            // rows past the last tile repeat it: the loads stay unconditional, their stores land in the idle image
+            if (!TKS_MODE(2)) {
+                store_y(ybuf + ((t + 1) & 1) * L::TILEB);
+                load_y(t + 2 < ntile ? t + 2 : ntile - 1);
+            }
             const char* yb = ybuf + (t & 1) * L::TILEB + c * L::ROWB + 16 * h;
             f32x16 acc0, acc1;
 #pragma unroll
@@ -493,33 +536,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         }
     };
 
-    // Plane staging by all selector threads: tile t + 2 is in registers while tile t + 1 is written to LDS.
-    constexpr int NTS = 64 * WM * SEL;
-    constexpr int TILE_CH = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile
-    constexpr int NV = (TILE_CH + NTS - 1) / NTS;
     const int stid = tid - 64 * WM;
-    tk_u32x4 pre[NV];
-    // Unconditional loads (a branch around a load makes the compiler wait for it on the spot): threads past the
-    // tile repeat its last chunk.
-    auto load_y = [&](int t) __attribute__((always_inline)) {
-        const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_CH;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            int e = stid + v * NTS;
-            e = e < TILE_CH ? e : TILE_CH - 1;
-            pre[v] = src[e];
-        }
-    };
-    auto store_y = [&](char* ytile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            int e = stid + v * NTS;
-            e = e < TILE_CH ? e : TILE_CH - 1;  // duplicates write the same values
-            const int row = e / F8;             // plane * 32 + item
-            const int kc = e % F8;
-            *reinterpret_cast<tk_u32x4*>(ytile + row * L::ROWB + 16 * kc) = pre[v];
-        }
-    };
 
     // Fill counts: wave-uniform, one byte per row, packed per half-wave (a count never exceeds CAP <= 255)
     static_assert(CAP <= 255, "fill counts are kept in bytes");
@@ -547,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             for (int q = 0; q < NROW / 4; ++q)
                 cnt_p[a][q] = (a == hh && q == (j >> 2)) ? ((cnt_p[a][q] & ~(0xffu << sh)) | ((unsigned)v << sh)) : cnt_p[a][q];
     };
-    int turn = 0;  // the buffer whose turn it is to be compacted early
+    int sched_next = 3;  // next item tile with a scheduled compaction
     auto counts_to_lds = [&]() __attribute__((always_inline)) {
         if (lane == 0) {
 #pragma unroll
@@ -619,7 +636,6 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         // Row by row, the compare result is the lane mask of the candidates, which also gives every candidate its
         // slot; counts are scalars.  A row whose buffer cannot take its candidates is deferred to the code below.
         unsigned defer = 0u;
-        bool pushed = false;
 #pragma unroll
         for (int j = 0; j < NROW; ++j) {
             unsigned long long mm = __ballot(sc[j] > thr_r[j]) & okm;
@@ -629,7 +645,6 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                 mm &= __ballot(((lmask[ur] >> c) & 1u) == 0u);
                 if (mm == 0ull) continue;
             }
-            pushed = true;
             const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
             const int pc0 = __builtin_popcount(m0), pc1 = __builtin_popcount(m1);
             const int n0 = cnt_get(0, j), n1 = cnt_get(1, j);
@@ -645,11 +660,10 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             cnt_add(0, j, pc0);
             cnt_add(1, j, pc1);
         }
-        // Buffers to compact now, bit 8*hh + j: those that cannot take this tile's candidates -- and, in a tile
-        // that gave this selector nothing to do, one buffer (taken in turn) that has gathered enough new entries:
-        // compacting it early costs nothing on the workgroup's critical path, raises its threshold sooner
-        // and mostly spares the forced compaction, which stalls every wave of the workgroup at the next barrier.
-        dbg_b = TKS_T();
+        // Buffers to compact now, bit 8*hh + j: those that cannot take this tile's candidates -- and, at tiles
+        // that every selector of the workgroup computes alike (a geometric schedule), all that have gathered
+        // enough new entries.  A compaction stalls every wave of the workgroup at the next barrier; on the
+        // schedule the selectors pay that together instead of one after the other, and the forced ones become rare.
         unsigned todo = 0u;
         if (defer != 0u) {
 #pragma unroll
@@ -661,9 +675,14 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                 if (cnt_get(0, j) + __builtin_popcount((unsigned)mm) > CAP) todo |= 1u << j;
                 if (cnt_get(1, j) + __builtin_popcount((unsigned)(mm >> 32)) > CAP) todo |= 1u << (8 + j);
             }
-        } else if (!pushed) {
-            turn = (turn + 1) & (2 * NROW - 1);
-            if (cnt_get_dyn(turn >> 3, turn & 7) >= k + TOPK_EARLY_COMPACT) todo = 1u << turn;
+        }
+        if (tt == sched_next) {
+            sched_next = tt + 1 + tt / 2;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int j = 0; j < NROW; ++j)
+                    if (cnt_get(hh, j) >= k + TOPK_EARLY_COMPACT) todo |= 1u << (8 * hh + j);
         }
         if (todo == 0u) return;
         while (todo != 0u) {
@@ -704,19 +723,12 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         }
     };
 
-    if (ntile > 0) {
-        load_y(0);
-        store_y(ybuf);
-    }
-    if (ntile > 1) load_y(1);
     __syncthreads();  // tile 0 is staged
     unsigned long long ds = 0, dsel = 0, dbar = 0, dst = 0;
     for (int t = 0; t < ntile; ++t) {
         const unsigned long long t0 = TKS_T();
-        if (t + 1 < ntile && !TKS_MODE(2)) store_y(ybuf + ((t + 1) & 1) * L::TILEB);  // waits for every load in flight
         mask_refill_commit();
         const unsigned long long t05 = TKS_T();
-        if (t + 2 < ntile && !TKS_MODE(2)) load_y(t + 2);
         mask_refill_issue();
         const unsigned long long t1 = TKS_T();
         dst += t05 - t0;
