@@ -215,13 +215,15 @@ __device__ __forceinline__ int compact_select(float* ss, int* ii, int n_in, int 
     const int iv = valid ? ii[lane] : 0;
     const uint32_t bits = __float_as_uint(sv);
     const uint32_t key = valid ? (bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u)) : 0u;
-    // two bits per step: the three trial values are independent compares, the chain is 16 steps long
+    // Two bits per step: the three trial values are independent compares.  The search stops at bit 12: the
+    // result is then a lower bound of the k-th best score, at most 2^-11 below it in relative terms, which is
+    // all a threshold needs (the entries between the two are simply kept).
     auto count_ge = [&](uint32_t trial) __attribute__((always_inline)) {
         return __builtin_popcountll(__builtin_amdgcn_uicmp(key, trial, 35 /* unsigned >= */));
     };
     uint32_t prefix = 0u;
 #pragma unroll
-    for (int b = 30; b >= 0; b -= 2) {
+    for (int b = 30; b >= 12; b -= 2) {
         const int c1 = count_ge(prefix | (1u << b));
         const int c2 = count_ge(prefix | (2u << b));
         const int c3 = count_ge(prefix | (3u << b));
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             for (int q = 0; q < NROW / 4; ++q)
                 cnt_p[a][q] = (a == hh && q == (j >> 2)) ? ((cnt_p[a][q] & ~(0xffu << sh)) | ((unsigned)v << sh)) : cnt_p[a][q];
     };
-    int sched_next = 3;  // next item tile with a scheduled compaction
+    int sched_next = 5;  // next item tile with a scheduled compaction: 5, 13, 33, 83, 208, 521, ...
     auto counts_to_lds = [&]() __attribute__((always_inline)) {
         if (lane == 0) {
 #pragma unroll
@@ -664,6 +666,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         // that every selector of the workgroup computes alike (a geometric schedule), all that have gathered
         // enough new entries.  A compaction stalls every wave of the workgroup at the next barrier; on the
         // schedule the selectors pay that together instead of one after the other, and the forced ones become rare.
+        dbg_b = TKS_T();
         unsigned todo = 0u;
         if (defer != 0u) {
 #pragma unroll
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             }
         }
         if (tt == sched_next) {
-            sched_next = tt + 1 + tt / 2;
+            sched_next = tt * 5 / 2 + 1;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
