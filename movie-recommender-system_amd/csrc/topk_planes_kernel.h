@@ -5,9 +5,9 @@
 // so selection work cannot hide behind it.  Here the scores that drive the
 // selection come from v_mfma_f32_32x32x16_bf16 instead: both factor matrices are
 // split into two bf16 planes (x ~ hi + mid, 16 significant bits) and a tile
-// accumulates the four plane products.  Such a score s~ differs from the
+// accumulates the three plane products hi*hi, hi*mid and mid*hi.  Such a score s~ differs from the
 // reference chain s = fma(q[f-1], y[f-1], ... ) by at most
-// eps = (c_f * 2^-24 + 2^-17) * ||q|| * max||y||, far below the spacing of the
+// eps = (c_f * 2^-24 + 2^-17 + 2^-18) * ||q|| * max||y||, far below the spacing of the
 // scores around rank k.  The selection is therefore run with a margin and the survivors
 // are scored again, exactly:
 //
@@ -26,7 +26,7 @@
 //
 // A workgroup owns 32*WM query rows.  Its WM "matrix" waves keep 32 queries each
 // as split MFMA A operands in registers, sweep the items in tiles of 32 and do
-// nothing but plane staging, operand reads, 4*F/16 MFMAs and four 16-byte stores
+// nothing but plane staging, operand reads, 3*F/16 MFMAs and four 16-byte stores
 // of the score tile per item tile.  Two "selector" waves per matrix wave consume the score
 // tile of the previous item tile and own all selection state (the matrix waves
 // also stage the next tile of the pre-split planes into LDS, double buffered): thresholds and fill
@@ -90,12 +90,13 @@ __device__ __forceinline__ f32x16 tk_mma(const tk_u32x4& a, const tk_u32x4& b, f
 }
 
 // |s~ - s| <= topk_eps_coef<F>() * ||q|| * max||y||: the factors' third bf16 planes, which are dropped
-// (|x - hi - mid| <= 2^-18 |x| on either side: 2^-17 in all), the F roundings of the fp32 chain and the
+// (|x - hi - mid| <= 2^-18 |x| on either side: 2^-17 in all), the mid * mid plane product, which is not
+// formed (|mid| <= 2^-9 |x|: 2^-18), the F roundings of the fp32 chain and the
 // roundings of the matrix pipe's accumulation -- the latter with a wide safety factor on the typical
 // (random-walk) error, which is below 2^-24 of sum |q_k y_k|.
 template <int F>
 constexpr float topk_eps_coef() {
-    return ((float)(8 * F + 64) * 5.9604644775390625e-8f + 7.62939453125e-6f) * 1.01f;
+    return ((float)(8 * F + 64) * 5.9604644775390625e-8f + 7.62939453125e-6f + 3.814697265625e-6f) * 1.01f;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -412,10 +413,16 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                 if (s + 1 < KS) fetch(bq[(s + 1) & 1], s + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const tk_u32x4(&b)[TOPK_NPLANES] = bq[s & 1];
-                acc0 = tk_mma(qh[s], b[0], acc0);  // hi hi
-                acc1 = tk_mma(qh[s], b[1], acc1);  // hi mid
-                acc0 = tk_mma(qm[s], b[1], acc0);  // mid mid
-                acc1 = tk_mma(qm[s], b[0], acc1);  // mid hi
+                // mid * mid is below 2^-18 of |q_k y_k| and left to the margin
+                if (s & 1) {
+                    acc1 = tk_mma(qh[s], b[0], acc1);  // hi hi
+                    acc0 = tk_mma(qh[s], b[1], acc0);  // hi mid
+                    acc1 = tk_mma(qm[s], b[0], acc1);  // mid hi
+                } else {
+                    acc0 = tk_mma(qh[s], b[0], acc0);  // hi hi
+                    acc1 = tk_mma(qh[s], b[1], acc1);  // hi mid
+                    acc0 = tk_mma(qm[s], b[0], acc0);  // mid hi
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             float* st = sbuf + ((t & 1) * WM + w) * L::ST + lane * 4;
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
     int* my_ring = ring + my_ur * RING;
     const int32_t* mrow = mask_indices;
     int cur = 0, tail = 0, mlen = 0, pend_base = -1;
-    int nxt = 0x7fffffff;
+    int nxt = 0x7fffffff, nxt2 = 0x7fffffff;  // the row's entries cur and cur + 1 (0x7fffffff: none, or not read yet)
     int rf[4] = {0, 0, 0, 0};
     const bool walker = mask_indptr != nullptr && lane < 2 * NROW && u0 + my_ur < nq;
     if (walker) {
@@ -513,7 +520,11 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         mlen = (int)(mask_indptr[u0 + my_ur + 1] - b);
         tail = mlen < RING ? mlen : RING;
         for (int e = 0; e < tail; ++e) my_ring[e] = mrow[e];
-        if (mlen > 0) nxt = mrow[0];
+        // read back from the ring, not from memory: a register that may still be waiting for a memory load
+        // would put a wait for all loads in flight (the refill's among them) into the walk
+        __builtin_amdgcn_wave_barrier();
+        if (mlen > 0) nxt = my_ring[0];
+        if (mlen > 1) nxt2 = my_ring[1];
     }
     if (lane < 2 * NROW) lmask[my_ur] = 0u;
     auto mask_refill_issue = [&]() __attribute__((always_inline)) {
@@ -583,8 +594,8 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         const int i0 = tt * BI;
         const int item = i0 + c;
         bool tile_liked = false;  // wave-uniform: some query of this selector has a liked item in the tile
+        unsigned mw = 0u;         // walker lane hh * NROW + j: liked bits of the tile for query row_of(r0 + j, hh)
         if (mask_indptr != nullptr) {
-            unsigned mw = 0u;
             if (lane < 2 * NROW) {
                 const int lim = i0 + BI;
                 bool dry = false;
@@ -592,8 +603,14 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                     const int bit = nxt - i0;
                     if (bit >= 0) mw |= 1u << bit;
                     ++cur;
-                    dry = cur >= tail && cur < mlen;
-                    nxt = cur < tail ? my_ring[cur & (RING - 1)] : 0x7fffffff;
+                    nxt = nxt2;  // read from the ring one consumption ago
+                    if (nxt == 0x7fffffff && cur < mlen) {  // not in the ring then: it may be by now
+                        if (cur < tail)
+                            nxt = my_ring[cur & (RING - 1)];
+                        else
+                            dry = true;
+                    }
+                    nxt2 = cur + 1 < tail ? my_ring[(cur + 1) & (RING - 1)] : 0x7fffffff;
                 }
                 // The ring ran dry inside a tile: fetch directly, and wait.  Kept out of the loop above so that
                 // no wait for memory lands on its path.
@@ -603,6 +620,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                             const int v = mrow[cur];
                             if (v >= lim) {
                                 nxt = v;
+                                nxt2 = 0x7fffffff;
                                 tail = cur + 1;
                                 break;
                             }
@@ -610,6 +628,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                             if (bit >= 0) mw |= 1u << bit;
                             if (++cur >= mlen) {
                                 nxt = 0x7fffffff;
+                                nxt2 = 0x7fffffff;
                                 tail = mlen;
                                 break;
                             }
@@ -618,10 +637,6 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                 }
             }
             tile_liked = __ballot(mw != 0u) != 0ull;
-            if (tile_liked) {
-                if (lane < 2 * NROW) lmask[my_ur] = mw;
-                __builtin_amdgcn_wave_barrier();
-            }
         }
         const float* sb = sbuf + ((tt & 1) * WM + m) * L::ST + lane * 4;
         float sc[NROW];
@@ -644,7 +659,9 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             if (mm == 0ull) continue;
             const int ur = row_of(r0 + j, h);
             if (tile_liked) {
-                mm &= __ballot(((lmask[ur] >> c) & 1u) == 0u);
+                const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)mw, j);
+                const unsigned l1 = (unsigned)__builtin_amdgcn_readlane((int)mw, NROW + j);
+                mm &= ~((unsigned long long)l0 | ((unsigned long long)l1 << 32));
                 if (mm == 0ull) continue;
             }
             const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
@@ -669,6 +686,10 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         dbg_b = TKS_T();
         unsigned todo = 0u;
         if (defer != 0u) {
+            if (tile_liked) {  // the deferred rows take the liked bits from LDS
+                if (lane < 2 * NROW) lmask[my_ur] = mw;
+                __builtin_amdgcn_wave_barrier();
+            }
 #pragma unroll
             for (int j = 0; j < NROW; ++j) {
                 if (!((defer >> j) & 1u)) continue;

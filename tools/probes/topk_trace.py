@@ -13,7 +13,7 @@ lib = _lib.require()
 buf = (ctypes.c_uint * (20 * 1024))()
 for wg in [int(a) for a in sys.argv[1:]] or [0]:
     lib.mirec_topk_debug_mode(wg << 8)
-    E.topk(X, Y, 20, None); torch.cuda.synchronize()
+    E.topk(X, Y, 20, Cui if os.environ.get("TRACE_MASK") else None); torch.cuda.synchronize()
     lib.mirec_topk_debug_trace(buf)
     tr = np.frombuffer(buf, dtype=np.uint32).reshape(20, 1024)[:, :844].astype(np.int64)
     sel, tile, stage, mat = tr[0:8], tr[8], tr[9:13], tr[16:20]
