@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak
 
 
 def parse_args():
@@ -258,9 +259,16 @@ def main():
         flops = 2.0 * n_local * I * W
         extra["top20_users_per_s"] = U / tk
         extra["top20_pass_ms"] = tk * 1e3
-        extra["topk_roofline"] = {"kernel": "topk_kernel<%d,%s>" % (W, "4,56" if args.topk <= 24 else "4,128" if args.topk <= 96 else "2,256"), "bound": "mfma",
-                                  "achieved": flops / tk / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": flops / tk / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        # widths 64/96/128 with k <= 24 select on bf16 matrix-core scores (three plane products per multiply-add
+        # of the score matrix) and re-score the survivors in fp32; everything else runs on the fp32 matrix pipe
+        planes = W in (64, 96, 128) and args.topk <= 24
+        peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if planes else MFMA_F32_PEAK_TFLOPS
+        kname = ("topk_planes_kernel<%d,4,64>" % W) if planes else "topk_kernel<%d,%s>" % (
+            W, "4,56" if args.topk <= 24 else "4,128" if args.topk <= 96 else "2,256")
+        extra["topk_roofline"] = {"kernel": kname, "bound": "mfma", "achieved": flops / tk / 1e12, "peak": peak,
+                                  "unit": "TFLOP/s", "frac": flops / tk / 1e12 / peak,
+                                  "note": "achieved = 2*users*items*f / time; peak = dense bf16 peak / 3 plane products"
+                                  if planes else "achieved = 2*users*items*f / time; peak = dense fp32 matrix peak"}
         del outs
 
     # ---- LightFM hybrid scoring (configs[4]): segment-sum + dot + top-20 for all users, rank 0's share

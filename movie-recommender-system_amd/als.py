@@ -123,7 +123,7 @@ class AlternatingLeastSquares:
     # -------------------------------------------------------------- inference
     def _device_items(self, dev: torch.device):
         if self._dev_items is None or self._dev_items.device != dev:
-            W = E.factor_width(self.factors, for_scoring=True)
+            W = E.scoring_width(self.factors, 1)
             self._dev_items = E.pad_factors(self.item_factors, W, dev)
         return self._dev_items
 

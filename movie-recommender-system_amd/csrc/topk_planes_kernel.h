@@ -1,5 +1,6 @@
 // Fused score + top-K on the bf16 matrix pipe with exact fp32 results (factor
-// widths 64, 96 and 128, k <= 24, plain scoring, caller workspace given).
+// widths that are multiples of 16 up to 128, k <= 24, plain scoring, caller
+// workspace given).
 //
 // The fp32 MFMA keeps the vector ALU of its SIMD busy for its whole duration,
 // so selection work cannot hide behind it.  Here the scores that drive the
@@ -593,6 +594,11 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
     auto select_tile = [&](int tt) __attribute__((always_inline)) {
         const int i0 = tt * BI;
         const int item = i0 + c;
+        // the scores are requested first: their way from LDS overlaps the liked-item walk
+        const float* sb = sbuf + ((tt & 1) * WM + m) * L::ST + lane * 4;
+        f32x4 scv[NROW / 4];
+#pragma unroll
+        for (int q = 0; q < NROW / 4; ++q) scv[q] = *reinterpret_cast<const f32x4*>(sb + (r0 / 4 + q) * 256);
         bool tile_liked = false;  // wave-uniform: some query of this selector has a liked item in the tile
         unsigned mw = 0u;         // walker lane hh * NROW + j: liked bits of the tile for query row_of(r0 + j, hh)
         if (mask_indptr != nullptr) {
@@ -638,15 +644,13 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             }
             tile_liked = __ballot(mw != 0u) != 0ull;
         }
-        const float* sb = sbuf + ((tt & 1) * WM + m) * L::ST + lane * 4;
         float sc[NROW];
 #pragma unroll
         for (int q = 0; q < NROW / 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (r0 / 4 + q) * 256);
-            sc[4 * q] = v[0];
-            sc[4 * q + 1] = v[1];
-            sc[4 * q + 2] = v[2];
-            sc[4 * q + 3] = v[3];
+            sc[4 * q] = scv[q][0];
+            sc[4 * q + 1] = scv[q][1];
+            sc[4 * q + 2] = scv[q][2];
+            sc[4 * q + 3] = scv[q][3];
         }
         dbg_a = TKS_T();
         const unsigned long long okm = (tt == ntile - 1) ? __ballot(item < ni) : ~0ull;
@@ -873,7 +877,7 @@ template <int F>
 int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
                 const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
                 float* out_scores, void* ws, size_t ws_bytes, hipStream_t stream) {
-    if constexpr (F == 64 || F == 96 || F == 128) {
+    if constexpr (F % 16 == 0 && F <= 128) {
         if (ws != nullptr && y_norm == nullptr && q_norm == nullptr && topk_planes_supported(F, k) && ni >= 2 * TOPK_BI) {
             MIREC_REQUIRE(ws_bytes >= topk_workspace_layout(nq, ni, F).bytes, MIREC_E_INVALID,
                           "mirec_topk: workspace of %zu bytes given, mirec_topk_workspace_bytes asks for %zu", ws_bytes,

@@ -14,7 +14,7 @@ constexpr int TOPK_PLANE_KMAX = 24;  // largest k the bf16-plane kernel serves
 constexpr int TOPK_NPLANES = 2;      // bf16 planes per factor matrix
 
 inline bool topk_planes_supported(int f, int k) {
-    return (f == 64 || f == 96 || f == 128) && k >= 1 && k <= TOPK_PLANE_KMAX;
+    return f >= 16 && f <= 128 && f % 16 == 0 && k >= 1 && k <= TOPK_PLANE_KMAX;
 }
 
 struct TopkWorkspace {

@@ -48,6 +48,16 @@ def factor_width(f: int, for_scoring: bool = False) -> int:
     return int(w)
 
 
+def scoring_width(f: int, k: int) -> int:
+    """Padded width for a top-k pass: the smallest supported width, moved up to a
+    multiple of 16 when that lets k <= 24 run on the bf16-plane kernel (zero
+    columns do not change a score: fma(0, 0, s) == s)."""
+    w = factor_width(f, for_scoring=True)
+    if k <= 24 and w <= 128 and w % 16:
+        w = factor_width(w + 8, for_scoring=True)
+    return w
+
+
 def pad_factors(a: np.ndarray, width: int, device: torch.device) -> torch.Tensor:
     """Upload [n, f] fp32 as a zero-padded [n, width] device matrix."""
     a = np.ascontiguousarray(a, dtype=np.float32)

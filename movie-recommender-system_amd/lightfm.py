@@ -138,7 +138,7 @@ class LightFMScorer:
         itf = self._check_features(item_features, self.item_embeddings.shape[0], self.item_embeddings.shape[0], "item")
         if user_rows is not None:
             uf = uf[np.atleast_1d(np.asarray(user_rows, dtype=np.int64))]
-        W = E.factor_width(nc + 2, for_scoring=True)
+        W = E.scoring_width(nc + 2, int(k))
         with self._lock, torch.cuda.device(dev):
             t = self._tables(dev)
             # operand rows [b_u, 1, e...] and [1, b_i, e...]: the MFMA chain then adds b_u, b_i, u_0 i_0, ...

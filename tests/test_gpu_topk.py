@@ -52,7 +52,7 @@ def test_topk_bit_exact(dev, nq, ni, f, k):
 
 @pytest.mark.parametrize("nq,ni,f,k", [
     (1, 64, 64, 1), (257, 3001, 64, 24), (300, 2000, 96, 10), (1000, 5000, 128, 20), (130, 70, 128, 24),
-    (33, 27278, 128, 20), (640, 1500, 90, 20),
+    (33, 27278, 128, 20), (640, 1500, 90, 20), (300, 4000, 16, 20), (515, 2500, 32, 24), (200, 1000, 48, 5),
 ])
 def test_topk_plane_kernel_matches_oracle_and_fp32_kernel(dev, nq, ni, f, k):
     """Widths 64 / 96 / 128 with k <= 24 and a workspace select on bf16 matrix-core
