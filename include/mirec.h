@@ -166,6 +166,17 @@ int mirec_lightfm_repr(const int64_t* indptr, const int32_t* indices, const floa
 int mirec_lightfm_predict(const float* urepr, const float* irepr, const int32_t* user_ids,
                           const int32_t* item_ids, int64_t n, int nc, float* out, mirec_stream_t stream);
 
+/* lightfm `predict_ranks`, the kernel under `auc_score`, `precision_at_k` and
+ * `recall_at_k` as called at hybrid_docker/utils.py:111-155: for every stored
+ * entry (u, i) of the test matrix (CSR, int64 row pointers), ranks[entry] = the
+ * number of items j != i that are not stored in the user's train row and score
+ * >= score(u, i), as a float.  urepr / irepr are [*, nc+1] with the bias in
+ * column nc; scores use the chain of mirec_lightfm_predict.  train_indptr may
+ * be null (nothing excluded). */
+int mirec_lightfm_ranks(const float* urepr, const float* irepr, int64_t nu, int64_t ni, int nc,
+                        const int64_t* test_indptr, const int32_t* test_indices, const int64_t* train_indptr,
+                        const int32_t* train_indices, float* ranks, mirec_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Held-out ranking evaluation over the top-k output (the evaluation cell of
  * notebooks/baseline_als.ipynb, cells 66ca94ea / fd92678d; LightFM's

@@ -127,6 +127,49 @@ class LightFMScorer:
                                                  E._ptr(out), E._stream_ptr()), "mirec_lightfm_predict")
             return out.cpu().numpy()
 
+    # ------------------------------------------------------------ predict_rank
+    def predict_rank(self, test_interactions, train_interactions=None, item_features=None, user_features=None,
+                     num_threads: int = 1, check_intersections: bool = True) -> sp.csr_matrix:
+        """LightFM's ``predict_rank``: a CSR matrix shaped like
+        ``test_interactions`` whose entries are the 0-based ranks of the test
+        interactions among the items that are not train positives of the user
+        (ties count against the interaction).  Computed on the device by
+        ``mirec_lightfm_ranks``; ``predict_ranks`` in lightfm 1.17's
+        ``_lightfm_fast`` is the statement it follows."""
+        test = sp.csr_matrix(test_interactions)
+        test.sort_indices()
+        train = None
+        if train_interactions is not None:
+            train = sp.csr_matrix(train_interactions)
+            train.sort_indices()
+            if train.shape != test.shape:
+                raise ValueError("train and test interactions differ in shape")
+            if check_intersections and test.multiply(train).nnz:
+                raise ValueError("Test interactions matrix and train interactions matrix share interactions")
+        dev = E.require_cuda(self.device)
+        nc = self.no_components
+        nu, ni = test.shape
+        uf = self._check_features(user_features, self.user_embeddings.shape[0], self.user_embeddings.shape[0], "user")
+        itf = self._check_features(item_features, self.item_embeddings.shape[0], self.item_embeddings.shape[0], "item")
+        if nu > uf.shape[0] or ni > itf.shape[0]:
+            raise ValueError("interactions exceed the number of feature rows")
+        lib = _lib.require()
+        with self._lock, torch.cuda.device(dev):
+            t = self._tables(dev)
+            ur = self._repr(uf[:nu], t["ue"], t["ub"], self.user_scale, nc + 1, 0, nc, -1, dev)
+            ir = self._repr(itf[:ni], t["ie"], t["ib"], self.item_scale, nc + 1, 0, nc, -1, dev)
+            tp = torch.from_numpy(test.indptr.astype(np.int64)).to(dev)
+            ti = torch.from_numpy(test.indices.astype(np.int32)).to(dev)
+            rp = ri = None
+            if train is not None:
+                rp = torch.from_numpy(train.indptr.astype(np.int64)).to(dev)
+                ri = torch.from_numpy(train.indices.astype(np.int32)).to(dev)
+            ranks = torch.zeros(max(test.nnz, 1), dtype=torch.float32, device=dev)
+            _lib.check(lib.mirec_lightfm_ranks(E._ptr(ur), E._ptr(ir), nu, ni, nc, E._ptr(tp), E._ptr(ti), E._ptr(rp),
+                                               E._ptr(ri), E._ptr(ranks), E._stream_ptr()), "mirec_lightfm_ranks")
+            data = ranks[:test.nnz].cpu().numpy()
+        return sp.csr_matrix((data, test.indices.copy(), test.indptr.copy()), shape=test.shape)
+
     # --------------------------------------------------------------- recommend
     def recommend(self, user_rows, user_features, item_features=None, k: int = 20):
         """Top-k items for each listed row of ``user_features`` (None = all
@@ -165,3 +208,72 @@ def compute_recommendations(user_id, state, top_k: int = 20, cold_start_tokens=N
         row = sp.csr_matrix((np.ones(len(cols), dtype=np.float32), ([0] * len(cols), cols)), shape=(1, n_feat))
         ids, _ = model.recommend(None, row, state["item_features"], top_k)
     return [state["inv_item_map"][int(i)] for i in ids[0] if i >= 0]
+
+
+# ---------------------------------------------------------------------------
+# lightfm.evaluation, as called at hybrid_docker/utils.py:111-155
+def _rows_with_interactions(test: sp.csr_matrix, values: np.ndarray, preserve_rows: bool) -> np.ndarray:
+    return values if preserve_rows else values[np.diff(test.indptr) > 0]
+
+
+def precision_at_k(model: LightFMScorer, test_interactions, train_interactions=None, k: int = 10, user_features=None,
+                   item_features=None, preserve_rows: bool = False, num_threads: int = 1,
+                   check_intersections: bool = True) -> np.ndarray:
+    """Per-user fraction of the top k that are test positives (``lightfm.evaluation.precision_at_k``)."""
+    ranks = model.predict_rank(test_interactions, train_interactions, item_features, user_features, num_threads,
+                               check_intersections)
+    ranks.data = np.less(ranks.data, k, ranks.data)
+    precision = np.squeeze(np.array(ranks.sum(axis=1)), axis=1) / k
+    return _rows_with_interactions(sp.csr_matrix(test_interactions), precision, preserve_rows)
+
+
+def recall_at_k(model: LightFMScorer, test_interactions, train_interactions=None, k: int = 10, user_features=None,
+                item_features=None, preserve_rows: bool = False, num_threads: int = 1,
+                check_intersections: bool = True) -> np.ndarray:
+    """Per-user fraction of the test positives that are in the top k (``lightfm.evaluation.recall_at_k``)."""
+    ranks = model.predict_rank(test_interactions, train_interactions, item_features, user_features, num_threads,
+                               check_intersections)
+    ranks.data = np.less(ranks.data, k, ranks.data)
+    test = sp.csr_matrix(test_interactions)
+    retrieved = np.squeeze(np.array(test.getnnz(axis=1)))
+    hit = np.squeeze(np.array(ranks.sum(axis=1)), axis=1)
+    if not preserve_rows:
+        keep = np.diff(test.indptr) > 0
+        return hit[keep] / retrieved[keep]
+    return hit / np.maximum(retrieved, 1)
+
+
+def auc_from_ranks(ranks: sp.csr_matrix, num_train_positives: np.ndarray) -> np.ndarray:
+    """lightfm's ``calculate_auc_from_rank``: per user, the probability that a
+    random test positive outranks a random negative; 0.5 where a class is
+    missing.  The terms are formed in float32 as in the library and summed in
+    float64 (the library's float32 running sum differs by rounding only)."""
+    n_users, n_items = ranks.shape
+    indptr = ranks.indptr.astype(np.int64)
+    num_pos = np.diff(indptr)
+    num_neg = n_items - (num_pos + num_train_positives.astype(np.int64))
+    rows = np.repeat(np.arange(n_users, dtype=np.int64), num_pos)
+    order = np.lexsort((ranks.data, rows))
+    sorted_ranks = ranks.data[order].astype(np.float32)
+    within = (np.arange(len(rows), dtype=np.int64) - indptr[rows]).astype(np.float32)
+    adj = np.maximum(sorted_ranks - within, np.float32(0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        terms = (np.float32(1) - adj / num_neg[rows].astype(np.float32)).astype(np.float32)
+    sums = np.zeros(n_users, dtype=np.float64)
+    np.add.at(sums, rows, terms.astype(np.float64))
+    auc = np.full(n_users, 0.5, dtype=np.float32)
+    ok = (num_pos > 0) & (num_neg != n_items)
+    auc[ok] = (sums[ok] / num_pos[ok]).astype(np.float32)
+    return auc
+
+
+def auc_score(model: LightFMScorer, test_interactions, train_interactions=None, user_features=None,
+              item_features=None, preserve_rows: bool = False, num_threads: int = 1,
+              check_intersections: bool = True) -> np.ndarray:
+    """``lightfm.evaluation.auc_score`` (hybrid_docker/utils.py:111-117,135-140)."""
+    ranks = model.predict_rank(test_interactions, train_interactions, item_features, user_features, num_threads,
+                               check_intersections)
+    test = sp.csr_matrix(test_interactions)
+    ntp = (np.zeros(test.shape[0], dtype=np.int32) if train_interactions is None
+           else np.asarray(sp.csr_matrix(train_interactions).getnnz(axis=1), dtype=np.int32))
+    return _rows_with_interactions(test, auc_from_ranks(ranks, ntp), preserve_rows)

@@ -18,7 +18,9 @@ from .oracle import (  # noqa: F401
     als_loss,
     build,
     gram,
+    lightfm_auc,
     lightfm_predict,
+    lightfm_ranks,
     lightfm_repr,
     lightfm_topk,
     num_threads,

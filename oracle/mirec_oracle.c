@@ -382,3 +382,61 @@ void oracle_lightfm_topk(const float* urepr, int64_t nu, const float* irepr, int
         free(scores);
     }
 }
+
+/* lightfm `predict_ranks` (lightfm/_lightfm_fast.pyx.template): for each user with test interactions, the
+ * predictions of its test items first, then every item that is not a train positive of the user adds one to
+ * the rank of each test interaction it is not itself and whose prediction it reaches (>=). */
+void oracle_lightfm_ranks(const float* urepr, const float* irepr, int64_t nu, int64_t ni, int nc,
+                          const int64_t* test_indptr, const int32_t* test_indices, const int64_t* train_indptr,
+                          const int32_t* train_indices, float* ranks) {
+#pragma omp parallel for schedule(dynamic, 10)
+    for (int64_t u = 0; u < nu; ++u) {
+        int64_t t0 = test_indptr[u], t1 = test_indptr[u + 1];
+        if (t0 == t1) continue;
+        const float* ur = urepr + u * (nc + 1);
+        float* pred = (float*)malloc(sizeof(float) * (size_t)(t1 - t0));
+        for (int64_t i = t0; i < t1; ++i) {
+            pred[i - t0] = lightfm_score(ur, irepr + (int64_t)test_indices[i] * (nc + 1), nc);
+            ranks[i] = 0.f;
+        }
+        int64_t r = train_indptr ? train_indptr[u] : 0, r1 = train_indptr ? train_indptr[u + 1] : 0;
+        for (int64_t item = 0; item < ni; ++item) {
+            /* in_positives: the train row is sorted, a cursor replaces the binary search */
+            while (r < r1 && train_indices[r] < item) ++r;
+            if (r < r1 && train_indices[r] == item) continue;
+            float p = lightfm_score(ur, irepr + item * (nc + 1), nc);
+            for (int64_t i = t0; i < t1; ++i)
+                if (item != test_indices[i] && p >= pred[i - t0]) ranks[i] += 1.0f;
+        }
+        free(pred);
+    }
+}
+
+static int flt_compare(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* lightfm `calculate_auc_from_rank`: per user, ranks sorted ascending, the i-th has i better positives above
+ * it; auc = mean over positives of 1 - (rank - i)/num_negatives in float32; 0.5 when a class is missing.
+ * rank_data is sorted in place, as in the library. */
+void oracle_lightfm_auc_from_ranks(const int64_t* indptr, int64_t nu, int64_t ni, const int32_t* num_train_positives,
+                                   float* rank_data, float* auc) {
+    for (int64_t u = 0; u < nu; ++u) {
+        int64_t a = indptr[u], b = indptr[u + 1];
+        int64_t num_pos = b - a;
+        int64_t num_neg = ni - (num_pos + num_train_positives[u]);
+        auc[u] = 0.f;
+        if (num_pos == 0 || num_neg == ni) {
+            auc[u] = 0.5f;
+            continue;
+        }
+        qsort(rank_data + a, (size_t)num_pos, sizeof(float), flt_compare);
+        for (int64_t i = 0; i < num_pos; ++i) {
+            float rank = rank_data[a + i] - (float)i;
+            if (rank < 0.f) rank = 0.f;
+            auc[u] += 1.0f - rank / (float)num_neg;
+        }
+        auc[u] /= (float)num_pos;
+    }
+}

@@ -213,3 +213,38 @@ def lightfm_topk(urepr: np.ndarray, irepr: np.ndarray, k: int):
                                 ctypes.c_int64(irepr.shape[0]), ctypes.c_int(nc), ctypes.c_int(k),
                                 _p(ids, _i32p), _p(sc, _f32p))
     return ids, sc
+
+
+def lightfm_ranks(urepr: np.ndarray, irepr: np.ndarray, test: sp.csr_matrix, train: Optional[sp.csr_matrix] = None) -> np.ndarray:
+    """lightfm `predict_rank`: one float per stored test entry (CSR order)."""
+    urepr, irepr = _f32(urepr), _f32(irepr)
+    nc = urepr.shape[1] - 1
+    t = sp.csr_matrix(test)
+    t.sort_indices()
+    tp = np.ascontiguousarray(t.indptr, dtype=np.int64)
+    ti = np.ascontiguousarray(t.indices, dtype=np.int32)
+    rp = ri = None
+    if train is not None:
+        r = sp.csr_matrix(train)
+        r.sort_indices()
+        rp = np.ascontiguousarray(r.indptr, dtype=np.int64)
+        ri = np.ascontiguousarray(r.indices, dtype=np.int32)
+    ranks = np.zeros(t.nnz, dtype=np.float32)
+    _load().oracle_lightfm_ranks(_p(urepr, _f32p), _p(irepr, _f32p), ctypes.c_int64(t.shape[0]), ctypes.c_int64(t.shape[1]),
+                                 ctypes.c_int(nc), _p(tp, _i64p), _p(ti, _i32p), _p(rp, _i64p), _p(ri, _i32p),
+                                 _p(ranks, _f32p))
+    return ranks
+
+
+def lightfm_auc(ranks: np.ndarray, test: sp.csr_matrix, train: Optional[sp.csr_matrix] = None,
+                preserve_rows: bool = False) -> np.ndarray:
+    """lightfm.evaluation.auc_score from the ranks of `lightfm_ranks`."""
+    t = sp.csr_matrix(test)
+    tp = np.ascontiguousarray(t.indptr, dtype=np.int64)
+    ntp = (np.zeros(t.shape[0], dtype=np.int32) if train is None
+           else np.ascontiguousarray(np.diff(sp.csr_matrix(train).indptr), dtype=np.int32))
+    data = np.array(ranks, dtype=np.float32, copy=True)
+    auc = np.zeros(t.shape[0], dtype=np.float32)
+    _load().oracle_lightfm_auc_from_ranks(_p(tp, _i64p), ctypes.c_int64(t.shape[0]), ctypes.c_int64(t.shape[1]),
+                                          _p(ntp, _i32p), _p(data, _f32p), _p(auc, _f32p))
+    return auc if preserve_rows else auc[np.diff(t.indptr) > 0]
