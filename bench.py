@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--no-topk", action="store_true")
+    ap.add_argument("--no-lightfm-train", action="store_true")
     ap.add_argument("--no-lightfm", action="store_true")
     return ap.parse_args()
 
@@ -261,7 +262,7 @@ def main():
         extra["top20_pass_ms"] = tk * 1e3
         # widths 64/96/128 with k <= 24 select on bf16 matrix-core scores (three plane products per multiply-add
         # of the score matrix) and re-score the survivors in fp32; everything else runs on the fp32 matrix pipe
-        planes = W in (64, 96, 128) and args.topk <= 24
+        planes = W % 16 == 0 and W <= 128 and args.topk <= 24
         peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if planes else MFMA_F32_PEAK_TFLOPS
         kname = ("topk_planes_kernel<%d,4,64>" % W) if planes else "topk_kernel<%d,%s>" % (
             W, "4,56" if args.topk <= 24 else "4,128" if args.topk <= 96 else "2,256")
@@ -285,7 +286,26 @@ def main():
         torch.cuda.synchronize()
         tl = time.perf_counter() - t0
         extra["lightfm_top20_users_per_s_per_gpu_incl_transfers"] = nu_l / tl
-        del sc, prob
+        del sc
+        # WARP training, one epoch over the interactions of the first 100 k users (the second of two calls is timed;
+        # feature / example uploads and the parameter download are inside the figure)
+        if not args.no_lightfm_train:
+            import scipy.sparse as sp
+            from movie_recommender_system_amd import LightFM
+            nu_t = min(100_000, nu_l)
+            ip_h = indptr[: nu_t + 1].cpu().numpy()
+            coo = sp.csr_matrix((np.ones(int(ip_h[-1]), dtype=np.float32), indices[: int(ip_h[-1])].cpu().numpy(), ip_h),
+                                shape=(nu_t, I)).tocoo()
+            uf_t = prob["user_features"][:nu_t]
+            m = LightFM(no_components=15, loss="warp", random_state=args.seed, learning_schedule="adagrad",
+                        item_alpha=1e-6, device=dev)
+            m.fit_partial(coo, user_features=uf_t, item_features=prob["item_features"], epochs=1)
+            t0 = time.perf_counter()
+            m.fit_partial(coo, user_features=uf_t, item_features=prob["item_features"], epochs=1)
+            extra["lightfm_warp_examples_per_s_incl_transfers"] = coo.nnz / (time.perf_counter() - t0)
+            extra["lightfm_warp_examples"] = int(coo.nnz)
+            del m, coo
+        del prob
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:

@@ -177,6 +177,29 @@ int mirec_lightfm_ranks(const float* urepr, const float* irepr, int64_t nu, int6
                         const int64_t* test_indptr, const int32_t* test_indices, const int64_t* train_indptr,
                         const int32_t* train_indices, float* ranks, mirec_stream_t stream);
 
+/* One epoch of LightFM WARP training with the adagrad schedule
+ * (`model.fit_partial(train, user_features=, item_features=, epochs=1,
+ * num_threads=4)` at hybrid_docker/utils.py:100-107; lightfm 1.17 `fit_warp`).
+ * item / user features and the positives (the train interactions, rows sorted)
+ * are CSR with int64 row pointers; the examples are (user_ids[e], item_ids[e])
+ * with y[e] > 0, visited in `order`; sample_weight may be null (ones).
+ * Parameters and their squared-gradient accumulators (initially one) are updated
+ * in place; no_components <= 63.  Examples run concurrently and update shared
+ * parameters without locks, as the library's OpenMP threads do; serial != 0 runs
+ * them one after the other in `order` (the sequential statement, for checking).
+ * Negatives are drawn from a counter-based generator keyed by (seed, example).
+ * ws: device scratch of mirec_lightfm_warp_workspace_bytes(max_sampled) bytes.
+ * The call synchronises the stream once (it uploads a small table). */
+size_t mirec_lightfm_warp_workspace_bytes(int max_sampled);
+int mirec_lightfm_warp_epoch(
+    const int64_t* if_indptr, const int32_t* if_indices, const float* if_data, int64_t n_items, int64_t n_item_features,
+    const int64_t* uf_indptr, const int32_t* uf_indices, const float* uf_data, int64_t n_user_features,
+    const int64_t* pos_indptr, const int32_t* pos_indices, const int32_t* user_ids, const int32_t* item_ids,
+    const float* y, const float* sample_weight, const int32_t* order, int64_t n_examples, float* item_emb,
+    float* item_emb_grad, float* item_bias, float* item_bias_grad, float* user_emb, float* user_emb_grad,
+    float* user_bias, float* user_bias_grad, int nc, double learning_rate, double item_alpha, double user_alpha,
+    int max_sampled, uint32_t seed, int serial, void* ws, size_t ws_bytes, mirec_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Held-out ranking evaluation over the top-k output (the evaluation cell of
  * notebooks/baseline_als.ipynb, cells 66ca94ea / fd92678d; LightFM's

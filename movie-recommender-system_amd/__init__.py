@@ -7,8 +7,8 @@ GPU; running anything numeric does, and fails loudly without one.
 """
 
 from .als import AlternatingLeastSquares  # noqa: F401
-from .lightfm import LightFMScorer  # noqa: F401
+from .lightfm import LightFM, LightFMScorer  # noqa: F401
 from .recommender import ALSRecommender  # noqa: F401
 
-__all__ = ["AlternatingLeastSquares", "LightFMScorer", "ALSRecommender"]
+__all__ = ["AlternatingLeastSquares", "LightFM", "LightFMScorer", "ALSRecommender"]
 __version__ = "0.1.0"

@@ -191,6 +191,130 @@ class LightFMScorer:
             return ids.cpu().numpy(), scores.cpu().numpy()
 
 
+class LightFM(LightFMScorer):
+    """The part of ``lightfm.LightFM`` the reference trains with
+    (``hybrid_docker/train.py:157``: ``LightFM(no_components=, loss='warp',
+    random_state=, learning_schedule='adagrad', item_alpha=1e-6)`` and
+    ``fit_partial(train, user_features=, item_features=, epochs=1,
+    num_threads=4)`` at ``hybrid_docker/utils.py:100-107``), on the device.
+    Everything a fitted model is asked for afterwards (``predict``,
+    ``predict_rank``, ``recommend``) is inherited from the scorer.
+
+    Examples of an epoch run concurrently and update shared parameters without
+    locks -- the library's Hogwild contract -- so two fits differ in the last
+    digits and parity with a sequential run is statistical; ``serial=True``
+    runs the examples one after the other and is reproducible bit for bit."""
+
+    def __init__(self, no_components: int = 10, k: int = 5, n: int = 10, learning_schedule: str = "adagrad",
+                 loss: str = "logistic", learning_rate: float = 0.05, rho: float = 0.95, epsilon: float = 1e-6,
+                 item_alpha: float = 0.0, user_alpha: float = 0.0, max_sampled: int = 10, random_state=None,
+                 device=None, serial: bool = False):
+        if loss != "warp":
+            raise NotImplementedError(f"loss={loss!r}: only 'warp' (the reference's setting) is built")
+        if learning_schedule != "adagrad":
+            raise NotImplementedError(f"learning_schedule={learning_schedule!r}: only 'adagrad' is built")
+        if not (item_alpha >= 0.0 and user_alpha >= 0.0 and no_components > 0 and max_sampled > 0):
+            raise ValueError("no_components and max_sampled must be positive, the alphas non-negative")
+        nc = int(no_components)
+        empty = np.zeros((0, nc), dtype=np.float32)
+        super().__init__(empty, np.zeros(0, np.float32), empty, np.zeros(0, np.float32), device=device)
+        self.loss, self.learning_schedule = loss, learning_schedule
+        self.learning_rate, self.rho, self.epsilon = float(learning_rate), float(rho), float(epsilon)
+        self.k, self.n = int(k), int(n)
+        self.item_alpha, self.user_alpha, self.max_sampled = float(item_alpha), float(user_alpha), int(max_sampled)
+        if random_state is None:
+            self.random_state = np.random.RandomState()
+        elif isinstance(random_state, np.random.RandomState):
+            self.random_state = random_state
+        else:
+            self.random_state = np.random.RandomState(random_state)
+        self.serial = bool(serial)
+        self.item_embedding_gradients = self.item_bias_gradients = None
+        self.user_embedding_gradients = self.user_bias_gradients = None
+
+    def _initialize(self, no_user_features: int, no_item_features: int) -> None:
+        # lightfm.LightFM._initialize: items first, then users; adagrad accumulators start at one
+        nc = self.no_components
+        rs = self.random_state
+        self.item_embeddings = ((rs.rand(no_item_features, nc) - 0.5) / nc).astype(np.float32)
+        self.item_embedding_gradients = np.ones((no_item_features, nc), dtype=np.float32)
+        self.item_biases = np.zeros(no_item_features, dtype=np.float32)
+        self.item_bias_gradients = np.ones(no_item_features, dtype=np.float32)
+        self.user_embeddings = ((rs.rand(no_user_features, nc) - 0.5) / nc).astype(np.float32)
+        self.user_embedding_gradients = np.ones((no_user_features, nc), dtype=np.float32)
+        self.user_biases = np.zeros(no_user_features, dtype=np.float32)
+        self.user_bias_gradients = np.ones(no_user_features, dtype=np.float32)
+
+    def fit(self, interactions, user_features=None, item_features=None, sample_weight=None, epochs: int = 1,
+            num_threads: int = 1, verbose: bool = False):
+        self.item_embedding_gradients = None  # start afresh
+        return self.fit_partial(interactions, user_features, item_features, sample_weight, epochs, num_threads, verbose)
+
+    def fit_partial(self, interactions, user_features=None, item_features=None, sample_weight=None, epochs: int = 1,
+                    num_threads: int = 1, verbose: bool = False):
+        coo = sp.coo_matrix(interactions)
+        if coo.dtype != np.float32:
+            coo = coo.astype(np.float32)
+        n_users, n_items = coo.shape
+        uf = sp.csr_matrix(_identity(n_users) if user_features is None else user_features, dtype=np.float32)
+        itf = sp.csr_matrix(_identity(n_items) if item_features is None else item_features, dtype=np.float32)
+        if uf.shape[0] < n_users or itf.shape[0] < n_items:
+            raise Exception("Number of feature rows does not cover the interactions")
+        if self.item_embedding_gradients is None:
+            self._initialize(uf.shape[1], itf.shape[1])
+        if uf.shape[1] != self.user_embeddings.shape[0] or itf.shape[1] != self.item_embeddings.shape[0]:
+            raise ValueError("Incorrect number of features in user_features / item_features")
+        if sample_weight is not None:
+            sw = sp.coo_matrix(sample_weight)
+            if sw.shape != coo.shape or not (np.array_equal(sw.row, coo.row) and np.array_equal(sw.col, coo.col)):
+                raise ValueError("Sample weight and interaction matrix entries must be in the same order")
+            sample_weight = np.ascontiguousarray(sw.data, dtype=np.float32)
+        if num_threads < 1:
+            raise ValueError("Number of threads must be 1 or larger.")
+        pos = sp.csr_matrix(coo)
+        pos.sort_indices()
+        dev = E.require_cuda(self.device)
+        lib = _lib.require()
+        nc = self.no_components
+        up = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(dev)
+        with self._lock, torch.cuda.device(dev):
+            d = {
+                "ifp": up(itf.indptr, np.int64), "ifi": up(itf.indices, np.int32), "ifd": up(itf.data, np.float32),
+                "ufp": up(uf.indptr, np.int64), "ufi": up(uf.indices, np.int32), "ufd": up(uf.data, np.float32),
+                "pp": up(pos.indptr, np.int64), "pi": up(pos.indices, np.int32),
+                "uid": up(coo.row, np.int32), "iid": up(coo.col, np.int32), "y": up(coo.data, np.float32),
+                "sw": None if sample_weight is None else up(sample_weight, np.float32),
+            }
+            names = ["item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients",
+                     "user_embeddings", "user_embedding_gradients", "user_biases", "user_bias_gradients"]
+            par = {n: up(getattr(self, n), np.float32) for n in names}
+            ws_bytes = int(lib.mirec_lightfm_warp_workspace_bytes(self.max_sampled))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            for _ in range(int(epochs)):
+                # one permutation and one generator seed per epoch from the model's random state, as the library draws them
+                order = np.arange(coo.nnz, dtype=np.int32)
+                self.random_state.shuffle(order)
+                seed = int(self.random_state.randint(0, np.iinfo(np.int32).max))
+                d_order = torch.from_numpy(order).to(dev)
+                _lib.check(lib.mirec_lightfm_warp_epoch(
+                    E._ptr(d["ifp"]), E._ptr(d["ifi"]), E._ptr(d["ifd"]), n_items, itf.shape[1],
+                    E._ptr(d["ufp"]), E._ptr(d["ufi"]), E._ptr(d["ufd"]), uf.shape[1],
+                    E._ptr(d["pp"]), E._ptr(d["pi"]), E._ptr(d["uid"]), E._ptr(d["iid"]), E._ptr(d["y"]), E._ptr(d["sw"]),
+                    E._ptr(d_order), coo.nnz,
+                    E._ptr(par["item_embeddings"]), E._ptr(par["item_embedding_gradients"]), E._ptr(par["item_biases"]),
+                    E._ptr(par["item_bias_gradients"]), E._ptr(par["user_embeddings"]),
+                    E._ptr(par["user_embedding_gradients"]), E._ptr(par["user_biases"]), E._ptr(par["user_bias_gradients"]),
+                    nc, self.learning_rate, self.item_alpha, self.user_alpha, self.max_sampled, seed,
+                    1 if self.serial else 0, E._ptr(ws), ws_bytes, E._stream_ptr()), "mirec_lightfm_warp_epoch")
+            for n in names:
+                setattr(self, n, par[n].cpu().numpy())
+            self._dev = {}  # the scorer's device tables are stale
+        if not all(np.isfinite(getattr(self, n)).all() for n in ("item_embeddings", "user_embeddings", "item_biases")):
+            raise ValueError("Not all estimated parameters are finite, your model may have diverged. "
+                             "Try decreasing the learning rate or normalising feature values and sample weights")
+        return self
+
+
 def compute_recommendations(user_id, state, top_k: int = 20, cold_start_tokens=None):
     """The request path of ``compute_recommendations``
     (``hybrid_docker/inference.py:129-200``) on the GPU scorer.  ``state`` holds

@@ -19,6 +19,8 @@ from .oracle import (  # noqa: F401
     build,
     gram,
     lightfm_auc,
+    lightfm_init,
+    lightfm_warp_epoch,
     lightfm_predict,
     lightfm_ranks,
     lightfm_repr,

@@ -440,3 +440,123 @@ void oracle_lightfm_auc_from_ranks(const int64_t* indptr, int64_t nu, int64_t ni
         auc[u] /= (float)num_pos;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LightFM WARP training, one epoch, sequential (lightfm 1.17 `fit_warp` / `warp_update` / `update_features` /
+ * `update_biases` of lightfm/_lightfm_fast.pyx.template with the adagrad schedule, reached from
+ * `model.fit_partial(..., epochs=1, num_threads=4)` at hybrid_docker/utils.py:100-107).  The library runs its
+ * examples Hogwild over OpenMP threads and draws negatives with rand_r; this statement runs them in the given
+ * order and draws negatives from a counter-based generator keyed by (seed, example), so that a run is a
+ * function of its inputs.  Arithmetic types follow the Cython source: parameters float32, the update
+ * expressions double.
+ *
+ * Per example (u, i+): representations with the lazy-regularisation scales, positive prediction; up to
+ * max_sampled negatives j: skip when score(j) <= score(i+) - 1; skip (and count) when j is a positive of u; else
+ * loss = weight * log(max(1, floor((n_items - 1) / sampled))) clipped at 10 and one adagrad step on the item
+ * biases (i+: -loss, j: +loss), the item embeddings (i+: -loss*u_c, j: +loss*u_c) and the user embeddings
+ * (loss * (j_c - i+_c)); the scales grow by (1 + alpha * mean learning rate).  `regularize` at the end of the
+ * epoch divides the parameters by the scales and resets them.  (Representations multiply by the scale and
+ * `regularize` divides by it: that is how the source is recalled; with the reference's item_alpha = 1e-6 and
+ * user_alpha = 0, hybrid_docker/train.py:157, the scales stay within 1e-4 of one either way.)
+ */
+static inline uint32_t warp_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+static void warp_repr(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row,
+                      const float* emb, const float* bias, double scale, int nc, float* out) {
+    for (int j = 0; j <= nc; ++j) out[j] = 0.f;
+    for (int64_t k = indptr[row]; k < indptr[row + 1]; ++k) {
+        int32_t f = indices[k];
+        float w = (float)(data[k] * scale);
+        for (int j = 0; j < nc; ++j) out[j] = fmaf(w, emb[(int64_t)f * nc + j], out[j]);
+        out[nc] = fmaf(w, bias[f], out[nc]);
+    }
+}
+
+static double warp_update_row(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row,
+                              float* param, float* grad, int stride, int col, double gradient, double lr, double alpha) {
+    double sum_lr = 0.0;
+    for (int64_t k = indptr[row]; k < indptr[row + 1]; ++k) {
+        int64_t at = (int64_t)indices[k] * stride + col;
+        double fw = data[k];
+        double local = lr / sqrt((double)grad[at]);
+        param[at] = (float)(param[at] - local * fw * gradient);
+        grad[at] = (float)(grad[at] + (gradient * fw) * (gradient * fw));
+        param[at] = (float)(param[at] * (1.0 + alpha * local));
+        sum_lr += local;
+    }
+    return sum_lr;
+}
+
+void oracle_lightfm_warp_epoch(
+    const int64_t* if_indptr, const int32_t* if_indices, const float* if_data, int64_t n_items,
+    const int64_t* uf_indptr, const int32_t* uf_indices, const float* uf_data,
+    const int64_t* pos_indptr, const int32_t* pos_indices,
+    const int32_t* user_ids, const int32_t* item_ids, const float* y, const float* sample_weight,
+    const int32_t* order, int64_t n_examples,
+    float* item_emb, float* item_emb_grad, float* item_bias, float* item_bias_grad, int64_t n_item_features,
+    float* user_emb, float* user_emb_grad, float* user_bias, float* user_bias_grad, int64_t n_user_features,
+    int nc, double learning_rate, double item_alpha, double user_alpha, int max_sampled, uint32_t seed,
+    double* scales /* [item_scale, user_scale] in/out */) {
+    float* ur = (float*)malloc(sizeof(float) * 3 * (size_t)(nc + 1));
+    float* pr = ur + nc + 1;
+    float* nr = pr + nc + 1;
+    double item_scale = scales[0], user_scale = scales[1];
+    for (int64_t e = 0; e < n_examples; ++e) {
+        int32_t row = order[e];
+        if (!(y[row] > 0.f)) continue;
+        int32_t u = user_ids[row], ip = item_ids[row];
+        double weight = sample_weight ? sample_weight[row] : 1.0;
+        warp_repr(uf_indptr, uf_indices, uf_data, u, user_emb, user_bias, user_scale, nc, ur);
+        warp_repr(if_indptr, if_indices, if_data, ip, item_emb, item_bias, item_scale, nc, pr);
+        float ppred = lightfm_score(ur, pr, nc);
+        uint32_t rng = warp_hash(seed ^ warp_hash((uint32_t)row + 0x9e3779b9u));
+        int sampled = 0;
+        while (sampled < max_sampled) {
+            ++sampled;
+            rng = warp_hash(rng + 0x6d2b79f5u);
+            int32_t neg = (int32_t)(rng % (uint32_t)n_items);
+            warp_repr(if_indptr, if_indices, if_data, neg, item_emb, item_bias, item_scale, nc, nr);
+            float npred = lightfm_score(ur, nr, nc);
+            if (npred > ppred - 1.f) {
+                int64_t a = pos_indptr[u], b = pos_indptr[u + 1];
+                while (a < b) {
+                    int64_t m = a + (b - a) / 2;
+                    if (pos_indices[m] < neg) a = m + 1; else b = m;
+                }
+                if (a < pos_indptr[u + 1] && pos_indices[a] == neg) continue;
+                double loss = weight * log(fmax(1.0, floor((double)(n_items - 1) / sampled)));
+                if (loss > 10.0) loss = 10.0;
+                double avg = 0.0;
+                avg += warp_update_row(if_indptr, if_indices, if_data, ip, item_bias, item_bias_grad, 1, 0, -loss, learning_rate, item_alpha);
+                avg += warp_update_row(if_indptr, if_indices, if_data, neg, item_bias, item_bias_grad, 1, 0, loss, learning_rate, item_alpha);
+                for (int c = 0; c < nc; ++c) {
+                    double uc = ur[c], pc = pr[c], ncp = nr[c];
+                    avg += warp_update_row(if_indptr, if_indices, if_data, ip, item_emb, item_emb_grad, nc, c, -loss * uc, learning_rate, item_alpha);
+                    avg += warp_update_row(if_indptr, if_indices, if_data, neg, item_emb, item_emb_grad, nc, c, loss * uc, learning_rate, item_alpha);
+                    avg += warp_update_row(uf_indptr, uf_indices, uf_data, u, user_emb, user_emb_grad, nc, c, loss * (ncp - pc), learning_rate, user_alpha);
+                }
+                double denom = (double)(nc + 1) * (double)((uf_indptr[u + 1] - uf_indptr[u]) + (if_indptr[ip + 1] - if_indptr[ip]) +
+                                                           (if_indptr[neg + 1] - if_indptr[neg]));
+                avg /= denom;
+                item_scale *= 1.0 + item_alpha * avg;
+                user_scale *= 1.0 + user_alpha * avg;
+                break;
+            }
+        }
+    }
+    /* regularize(): fold the scales into the parameters */
+    for (int64_t i = 0; i < n_item_features; ++i) {
+        for (int j = 0; j < nc; ++j) item_emb[i * nc + j] = (float)(item_emb[i * nc + j] / item_scale);
+        item_bias[i] = (float)(item_bias[i] / item_scale);
+    }
+    for (int64_t i = 0; i < n_user_features; ++i) {
+        for (int j = 0; j < nc; ++j) user_emb[i * nc + j] = (float)(user_emb[i * nc + j] / user_scale);
+        user_bias[i] = (float)(user_bias[i] / user_scale);
+    }
+    scales[0] = 1.0;
+    scales[1] = 1.0;
+    free(ur);
+}

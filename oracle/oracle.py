@@ -248,3 +248,57 @@ def lightfm_auc(ranks: np.ndarray, test: sp.csr_matrix, train: Optional[sp.csr_m
     _load().oracle_lightfm_auc_from_ranks(_p(tp, _i64p), ctypes.c_int64(t.shape[0]), ctypes.c_int64(t.shape[1]),
                                           _p(ntp, _i32p), _p(data, _f32p), _p(auc, _f32p))
     return auc if preserve_rows else auc[np.diff(t.indptr) > 0]
+
+
+def lightfm_init(n_user_features: int, n_item_features: int, no_components: int, random_state: int):
+    """LightFM._initialize (lightfm/lightfm.py) for the adagrad schedule: embeddings
+    (rand - 0.5) / no_components in float32, items first; biases zero; squared-gradient
+    accumulators one."""
+    rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    nc = no_components
+    st = {
+        "item_embeddings": ((rs.rand(n_item_features, nc) - 0.5) / nc).astype(np.float32),
+        "item_embedding_gradients": np.ones((n_item_features, nc), dtype=np.float32),
+        "item_biases": np.zeros(n_item_features, dtype=np.float32),
+        "item_bias_gradients": np.ones(n_item_features, dtype=np.float32),
+    }
+    st.update({
+        "user_embeddings": ((rs.rand(n_user_features, nc) - 0.5) / nc).astype(np.float32),
+        "user_embedding_gradients": np.ones((n_user_features, nc), dtype=np.float32),
+        "user_biases": np.zeros(n_user_features, dtype=np.float32),
+        "user_bias_gradients": np.ones(n_user_features, dtype=np.float32),
+    })
+    return st
+
+
+def lightfm_warp_epoch(state: dict, interactions: sp.coo_matrix, user_features: sp.csr_matrix,
+                       item_features: sp.csr_matrix, order: np.ndarray, seed: int, learning_rate: float = 0.05,
+                       item_alpha: float = 0.0, user_alpha: float = 0.0, max_sampled: int = 10,
+                       sample_weight: Optional[np.ndarray] = None) -> None:
+    """One sequential WARP epoch over the examples of `interactions` (COO) in `order`; `state` is
+    updated in place."""
+    coo = sp.coo_matrix(interactions)
+    uf, itf = sp.csr_matrix(user_features), sp.csr_matrix(item_features)
+    pos = sp.csr_matrix(interactions)
+    pos.sort_indices()
+    nc = state["item_embeddings"].shape[1]
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    ufp, ufi, ufd = a(uf.indptr, np.int64), a(uf.indices, np.int32), a(uf.data, np.float32)
+    ifp, ifi, ifd = a(itf.indptr, np.int64), a(itf.indices, np.int32), a(itf.data, np.float32)
+    pp, pi = a(pos.indptr, np.int64), a(pos.indices, np.int32)
+    uid, iid, y = a(coo.row, np.int32), a(coo.col, np.int32), a(coo.data, np.float32)
+    sw = None if sample_weight is None else a(sample_weight, np.float32)
+    od = a(order, np.int32)
+    scales = np.array([1.0, 1.0], dtype=np.float64)
+    for k in state:
+        assert state[k].dtype == np.float32 and state[k].flags.c_contiguous
+    _load().oracle_lightfm_warp_epoch(
+        _p(ifp, _i64p), _p(ifi, _i32p), _p(ifd, _f32p), ctypes.c_int64(itf.shape[0]),
+        _p(ufp, _i64p), _p(ufi, _i32p), _p(ufd, _f32p), _p(pp, _i64p), _p(pi, _i32p),
+        _p(uid, _i32p), _p(iid, _i32p), _p(y, _f32p), _p(sw, _f32p), _p(od, _i32p), ctypes.c_int64(len(od)),
+        _p(state["item_embeddings"], _f32p), _p(state["item_embedding_gradients"], _f32p),
+        _p(state["item_biases"], _f32p), _p(state["item_bias_gradients"], _f32p), ctypes.c_int64(itf.shape[1]),
+        _p(state["user_embeddings"], _f32p), _p(state["user_embedding_gradients"], _f32p),
+        _p(state["user_biases"], _f32p), _p(state["user_bias_gradients"], _f32p), ctypes.c_int64(uf.shape[1]),
+        ctypes.c_int(nc), ctypes.c_double(learning_rate), ctypes.c_double(item_alpha), ctypes.c_double(user_alpha),
+        ctypes.c_int(max_sampled), ctypes.c_uint32(seed & 0xffffffff), scales.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
