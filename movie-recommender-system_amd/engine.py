@@ -175,7 +175,14 @@ class SweepPlan:
         dev = csr.indptr.device
         if short_max is None:
             table_bytes = csr.shape[1] * self.f * 4
-            short_max = ALL_ROWS if table_bytes <= SHORT_TABLE_BYTES else max(lib.mirec_als_short_cache_rows(self.f), 0)
+            # Measured at f = 128 (tools/microbench.py sweep --short-max): with the gathered table on chip (L2 /
+            # Infinity Cache) the matrix-free kernel wins up to about a thousand entries per row; with a larger
+            # table its four passes of gathers cost more, and the explicit Gram takes over from about 256 -- but
+            # rows of a few dozen entries stay far cheaper matrix-free whatever the table (2 M users x 60 entries
+            # against a 102 MB / 410 MB table: 18.7 / 21.1 ms, against 49 / 50 ms through the Gram kernel).
+            # The Gram's cost per entry grows with f^2, a gather's with f: the limits scale with f.
+            limit = 1024 if table_bytes <= SHORT_TABLE_BYTES else 256
+            short_max = max(limit * self.f // 128, int(lib.mirec_als_short_cache_rows(self.f)), 32)
         self.short_max = int(short_max)
         nbytes = lib.mirec_als_plan_bytes(nrows, csr.nnz, int(chunk_nnz))
         self.plan = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
