@@ -202,18 +202,30 @@ def main():
     # rank's blocks over the summed duration of their launches.
     u_rows, u_nnz, u_short, u_chunks = eng.user_totals()
 
-    def side(tag, rows, nz):
+    def split_by_kernel(plans):
+        """(rows, entries) solved by the matrix-free kernel and by the explicit-Gram kernel over these plans."""
+        rs = ns = rm = nm = 0
+        for p in plans:
+            if p is None:
+                continue
+            ln = p.csr.indptr[1:] - p.csr.indptr[:-1]
+            short = ln <= p.short_max
+            rs += int(short.sum())
+            ns += int(ln[short].sum())
+            rm += int((~short).sum())
+            nm += int(ln[~short].sum())
+        return (rs, ns), (rm, nm)
+
+    def side(tag, plans):
         out = []
         t_s, c_s = times.get(tag + "_short", (0.0, 0))
         t_m, c_m = times.get(tag + "_main", (0.0, 0))
-        # at the benchmark shape one side is all matrix-free rows and the other all explicit-Gram rows
-        if c_s and not c_m:
-            out.append(("als_short_kernel", sweep_bytes(nz, rows, F), t_s / args.steps, c_s))
-        elif c_m and not c_s:
-            out.append(("als_gram_cg_kernel", sweep_bytes(nz, rows, F), t_m / args.steps, c_m))
-        elif c_m and c_s:
-            out.append(("als_short_kernel", None, t_s / args.steps, c_s))
-            out.append(("als_gram_cg_kernel", None, t_m / args.steps, c_m))
+        (rs, ns), (rm, nm) = split_by_kernel(plans)
+        # algorithmic bytes of the rows each kernel solved
+        if c_s:
+            out.append(("als_short_kernel", sweep_bytes(ns, rs, F), t_s / args.steps, c_s))
+        if c_m:
+            out.append(("als_gram_cg_kernel", sweep_bytes(nm, rm, F), t_m / args.steps, c_m))
         return out
 
     # HBM-side bytes per launch cannot be read from inside this process: they come from separate
@@ -237,9 +249,8 @@ def main():
             break  # the newest capture of this workload has no such kernel: nothing older applies
         return None
 
-    entries = [(tag, k, b, ms, n) for tag, rows, nz in (("user", u_rows, u_nnz),
-                                                        ("item", eng.Ciu_local.shape[0], eng.Ciu_local.nnz))
-               for (k, b, ms, n) in side(tag, rows, nz)]
+    entries = [(tag, k, b, ms, n) for tag, plans in (("user", eng.plans_u), ("item", [eng.plan_i]))
+               for (k, b, ms, n) in side(tag, plans)]
     rl_all = []
     for tag, k, b, ms, n in entries:
         gbs = (b / (ms * 1e-3) / 1e9) if (b and ms > 0) else None
