@@ -605,7 +605,26 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             if (lane < 2 * NROW) {
                 const int lim = i0 + BI;
                 bool dry = false;
-                while (nxt < lim) {
+                // The common case -- at most one liked item of a query in a tile -- without a loop and without
+                // waiting for LDS: the entry after the one consumed is already in a register, the one after that is
+                // requested now and not looked at before the next tile.
+                bool more = false;
+                if (nxt < lim) {
+                    const int bit = nxt - i0;
+                    if (bit >= 0) mw |= 1u << bit;
+                    ++cur;
+                    nxt = nxt2;
+                    nxt2 = cur + 1 < tail ? my_ring[(cur + 1) & (RING - 1)] : 0x7fffffff;
+                    more = nxt < lim || (nxt == 0x7fffffff && cur < mlen);
+                }
+                if (__ballot(more) != 0ull) {
+                if (more && nxt == 0x7fffffff && cur < mlen) {  // not read when it was prefetched: it may be there by now
+                    if (cur < tail)
+                        nxt = my_ring[cur & (RING - 1)];
+                    else
+                        dry = true;
+                }
+                while (more && nxt < lim) {
                     const int bit = nxt - i0;
                     if (bit >= 0) mw |= 1u << bit;
                     ++cur;
@@ -640,6 +659,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                             }
                         }
                     }
+                }
                 }
             }
             tile_liked = __ballot(mw != 0u) != 0ull;
