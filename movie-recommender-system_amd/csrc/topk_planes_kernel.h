@@ -47,13 +47,11 @@ namespace mirec {
 // mirec_topk_debug_read (tools/probes/topk_phase_timing.py).
 #ifdef MIREC_DEBUG_TIMING
 static __device__ unsigned long long mirec_topk_dbg[16];
-static __device__ int mirec_topk_dbg_mode;  // experiment switches: 1 no selection, 2 no staging, 4 no MFMA
+static __device__ int mirec_topk_dbg_mode;  // bits 8 and up: the workgroup whose tiles are traced
 static __device__ unsigned mirec_topk_trace[20][1024];  // per tile, of workgroup mirec_topk_dbg_mode >> 8
 #define TKS_T() __builtin_readcyclecounter()
-#define TKS_MODE(bit) ((mirec_topk_dbg_mode & (bit)) != 0)
 #else
 #define TKS_T() 0ull
-#define TKS_MODE(bit) false
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 tk_bf16x8;
@@ -390,10 +388,8 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         for (int t = 0; t < ntile; ++t) {
             const unsigned long long t0 = TKS_T();
             // rows past the last tile repeat it: the loads stay unconditional, their stores land in the idle image
-            if (!TKS_MODE(2)) {
-                store_y(ybuf + ((t + 1) & 1) * L::TILEB);
-                load_y(t + 2 < ntile ? t + 2 : ntile - 1);
-            }
+            store_y(ybuf + ((t + 1) & 1) * L::TILEB);
+            load_y(t + 2 < ntile ? t + 2 : ntile - 1);
             const char* yb = ybuf + (t & 1) * L::TILEB + c * L::ROWB + 16 * h;
             f32x16 acc0, acc1;
 #pragma unroll
@@ -408,7 +404,6 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                 for (int p = 0; p < TOPK_NPLANES; ++p) dst[p] = *reinterpret_cast<const tk_u32x4*>(yb + p * L::PLANEB + 32 * s);
             };
             fetch(bq[0], 0);
-            if (!TKS_MODE(4))
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (s + 1 < KS) fetch(bq[(s + 1) & 1], s + 1);
@@ -780,7 +775,7 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         mask_refill_issue();
         const unsigned long long t1 = TKS_T();
         dst += t05 - t0;
-        if (t >= 1 && !TKS_MODE(1)) select_tile(t - 1);
+        if (t >= 1) select_tile(t - 1);
         const unsigned long long t2 = TKS_T();
         __syncthreads();  // score tile t is complete; plane tile t + 1 is staged
         ds += t1 - t0;
