@@ -49,6 +49,19 @@ def test_abi_rejects_bad_arguments_without_touching_a_device():
 
 
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-device failure mode")
+def test_scoring_width_and_topk_workspace_sizes():
+    """Widths for a top-k pass: the smallest supported one, moved up to a multiple of 16 where that puts k <= 24
+    on the bf16-plane kernel; the workspace query answers 0 wherever that kernel does not apply."""
+    from movie_recommender_system_amd import engine as E, _lib
+    lib = _lib.require()
+    assert [E.scoring_width(f, 20) for f in (5, 17, 20, 40, 64, 100, 128, 130)] == [16, 32, 32, 48, 64, 128, 128, 160]
+    assert E.scoring_width(17, 100) == 24 and E.scoring_width(128, 100) == 128
+    hot = lib.mirec_topk_workspace_bytes
+    assert hot(1000, 27000, 128, 20) == 256 + 4096 + 844 * 2 * 32 * 128 * 2
+    assert hot(1000, 27000, 128, 25) == 0 and hot(1000, 27000, 160, 20) == 0 and hot(1000, 27000, 24, 20) == 0
+    assert hot(0, 27000, 128, 20) == 0 and hot(1000, 0, 128, 20) == 0
+
+
 def test_numeric_calls_fail_loudly_without_a_gpu():
     M = sp.csr_matrix(np.array([[1, 0, 1], [0, 1, 0]], dtype=np.float32))
     model = AlternatingLeastSquares(factors=2, iterations=1, random_state=42)
