@@ -303,7 +303,7 @@ def main():
         flops = 2.0 * n_local * I * W
         extra["top20_users_per_s"] = U / tk
         extra["top20_pass_ms"] = tk * 1e3
-        # widths 64/96/128 with k <= 24 select on bf16 matrix-core scores (three plane products per multiply-add
+        # widths that are multiples of 16 up to 128 with k <= 24 select on bf16 matrix-core scores (three plane products per multiply-add
         # of the score matrix) and re-score the survivors in fp32; everything else runs on the fp32 matrix pipe
         planes = W % 16 == 0 and W <= 128 and args.topk <= 24
         peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if planes else MFMA_F32_PEAK_TFLOPS

@@ -6,11 +6,11 @@
 // so selection work cannot hide behind it.  Here the scores that drive the
 // selection come from v_mfma_f32_32x32x16_bf16 instead: both factor matrices are
 // split into two bf16 planes (x ~ hi + mid, 16 significant bits) and a tile
-// accumulates the three plane products hi*hi, hi*mid and mid*hi.  Such a score s~ differs from the
-// reference chain s = fma(q[f-1], y[f-1], ... ) by at most
-// eps = (c_f * 2^-24 + 2^-17 + 2^-18) * ||q|| * max||y||, far below the spacing of the
-// scores around rank k.  The selection is therefore run with a margin and the survivors
-// are scored again, exactly:
+// accumulates the three plane products hi*hi, hi*mid and mid*hi.  Such a score
+// s~ differs from the reference chain s = fma(q[f-1], y[f-1], ... ) by at most
+// eps = (c_f * 2^-24 + 2^-17 + 2^-18) * ||q|| * max||y||, far below the spacing
+// of the scores around rank k.  The selection is therefore run with a margin
+// and the survivors are scored again, exactly:
 //
 //   * tau~ = k-th best s~ seen by a query so far.  At most k - 1 items have
 //     s > s_(k), so tau~ <= s_(k) + eps at all times, while every member of the
@@ -27,15 +27,16 @@
 //
 // A workgroup owns 32*WM query rows.  Its WM "matrix" waves keep 32 queries each
 // as split MFMA A operands in registers, sweep the items in tiles of 32 and do
-// nothing but plane staging, operand reads, 3*F/16 MFMAs and four 16-byte stores
-// of the score tile per item tile.  Two "selector" waves per matrix wave consume the score
-// tile of the previous item tile and own all selection state (the matrix waves
-// also stage the next tile of the pre-split planes into LDS, double buffered): thresholds and fill
-// counts in registers, candidates found with one ballot per query row (which
-// also assigns the slots -- no atomics), buffers compacted by a wave-wide
-// bit-serial k-th-best search (no sort) only when a tile's candidates would not
-// fit.  One workgroup barrier per item tile separates producers and consumers
-// of the double-buffered images.
+// nothing but plane staging (global -> registers -> LDS, double buffered),
+// operand reads, 3*F/16 MFMAs and four 16-byte stores of the score tile per item
+// tile.  Two "selector" waves per matrix wave consume the score tile of the
+// previous item tile and own all selection state: thresholds in registers, fill
+// counts as packed scalars, the candidates of a query row straight from the
+// compare's lane mask (which also assigns their slots -- no atomics), liked
+// items from a per-query cursor fed by a small LDS ring, buffers compacted by a
+// digit-serial k-th-best search (no sort) when a tile's candidates would not
+// fit and on a tile schedule that all selectors share.  One workgroup barrier
+// per item tile separates producers and consumers of the double-buffered images.
 #pragma once
 #include "topk_kernel.h"
 #include "topk_workspace.h"
