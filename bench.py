@@ -153,10 +153,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # (the two overrides exist for rehearsing the multi-rank path on a one-GPU box: tools/rehearse_multi_rank.py)
+    local_rank = int(os.environ.get("MIREC_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MIREC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:

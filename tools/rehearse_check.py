@@ -1,0 +1,68 @@
+"""Two ranks on one GPU (gloo, host-staged collectives as in tools/rehearse_multi_rank.py): the factors after two
+sharded iterations must equal, bit for bit, those of a one-rank run of the same problem.  Launch with
+torch.distributed.run --nproc-per-node 2."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from movie_recommender_system_amd import dist as D, engine as E, synth  # noqa: E402
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+_ag_into, _ag = dist.all_gather_into_tensor, dist.all_gather
+
+
+def _into(out, inp, group=None, async_op=False):
+    host_out = torch.empty(out.shape, dtype=out.dtype)
+    _ag_into(host_out, inp.detach().cpu(), group=group)
+    out.copy_(host_out)
+    return _Done()
+
+
+def _list(outs, inp, group=None, async_op=False):
+    host = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+    _ag(host, inp.detach().cpu(), group=group)
+    for o, h in zip(outs, host):
+        o.copy_(h)
+    return _Done()
+
+
+dist.all_gather_into_tensor, dist.all_gather = _into, _list
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+U, I, f = 60_000, 5_000, 128
+indptr, indices, data = synth.interactions_torch(7, U, I, 40.0, dev)
+Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
+Ciu = Cui.transpose()
+rs = np.random.RandomState(7)
+X0 = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, f, dev)
+Y0 = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, f, dev)
+
+
+def run(r, w):
+    drv, eng = D.gpu_driver(Cui, Ciu, X0.clone(), Y0.clone(), 0.01, 3, r, w)
+    for _ in range(2):
+        drv.iteration()
+    torch.cuda.synchronize()
+    return drv.X.clone(), drv.Y.clone()
+
+
+Xs, Ys = run(rank, world)
+if rank == 0:
+    X1, Y1 = run(0, 1)
+    ok = torch.equal(Xs, X1) and torch.equal(Ys, Y1)
+    print("world", world, "vs 1: factors bit-identical:", ok, "| max abs diff X", float((Xs - X1).abs().max()), "Y",
+          float((Ys - Y1).abs().max()))
+    if not ok:
+        sys.exit(1)
+dist.barrier()
