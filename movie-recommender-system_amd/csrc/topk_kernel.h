@@ -14,8 +14,9 @@
 // (one LDS atomic reserves the slot); when a reservation fails the full buffers
 // are compacted by a wave-wide rank sort under the order (score desc, item
 // asc), which also raises tau, and the push is retried (CAP >= k + 32, so all
-// 32 lanes of a tile row fit after a compaction).  Items arrive in ascending index order, so a later item that ties the
-// k-th best never displaces it and `score > tau` is exact.  Liked items are
+// 32 lanes of a tile row fit after a compaction).  Tiles arrive in ascending index order, so an item that ties the
+// k-th best of earlier tiles never displaces it and the register test `score > tau` is exact; within a tile the
+// push order is arbitrary, so the push itself compares (score, index) with the k-th best.  Liked items are
 // found by a per-query cursor over the (ascending) mask row and turned into
 // -FLT_MAX only when they come up as candidates.
 //
@@ -281,7 +282,10 @@ __global__ __launch_bounds__(64 * WAVES) void topk_kernel(
                 }
                 const int ur = (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (mask_indptr != nullptr && ((lmask[ur] >> c) & 1u)) s = -FLT_MAX;
-                if (s > tau[ur]) {
+                // A compaction in the middle of a tile can leave a later item of this same tile as the k-th
+                // best; an equal score with a smaller index still beats it.
+                const float t = tau[ur];
+                if (s > t || (s == t && (int)item < sel_i[ur * CAP + k - 1])) {
                     const int pos = atomicAdd(&cnt[ur], 1);
                     if (pos < CAP) {
                         sel_s[ur * CAP + pos] = s;

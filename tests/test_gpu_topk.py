@@ -272,3 +272,18 @@ def test_lightfm_scoring_bit_exact(dev):
     oid, _ = oracle.lightfm_topk(cold, ir, 20)
     assert recs == [f"movie{i}" for i in oid[0]]
     assert compute_recommendations("u42", state, 20) == [f"movie{i}" for i in ids[0]]
+
+
+def test_topk_tie_at_kth_place_within_one_tile(dev):
+    """Cases a randomised run found (tools/fuzz_parity.py, seed 3): integer-valued or duplicated factors give
+    many equal scores; when a buffer is compacted in the middle of an item tile, an item of that tile that
+    ties the new k-th best but has the smaller index must still displace it."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for case in (55300, 49398, 80351, 61241):
+        ok, desc = fz.case_topk(np.random.default_rng([3, case]))
+        assert ok, f"case {case}: {desc}"
