@@ -287,3 +287,20 @@ def test_topk_tie_at_kth_place_within_one_tile(dev):
     for case in (55300, 49398, 80351, 61241):
         ok, desc = fz.case_topk(np.random.default_rng([3, case]))
         assert ok, f"case {case}: {desc}"
+
+
+def test_randomised_parity_fixed_seed(dev):
+    """A bounded, fixed-seed run of the randomised differential tool: 400 top-K and 400 half-sweep cases
+    over random shapes, widths, k, filters, tie patterns and row lengths (deterministic: every case has a
+    random stream of its own)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for i in range(400):
+        ok, desc = fz.case_topk(np.random.default_rng([11, i]))
+        assert ok, f"top-K case {i}: {desc}"
+        ok, desc = fz.case_sweep(np.random.default_rng([12, i]))
+        assert ok, f"half-sweep case {i}: {desc}"
