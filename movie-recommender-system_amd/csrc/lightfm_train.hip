@@ -233,6 +233,7 @@ extern "C" int mirec_lightfm_warp_epoch(
     MIREC_REQUIRE(nc >= 1 && nc <= 63, MIREC_E_UNSUPPORTED, "mirec_lightfm_warp_epoch: no_components must be 1..63 (got %d)", nc);
     MIREC_REQUIRE(n_items >= 1 && n_items < ((int64_t)1 << 31) && n_examples >= 0 && max_sampled >= 1, MIREC_E_INVALID,
                   "mirec_lightfm_warp_epoch: bad sizes");
+    if (n_examples == 0) return MIREC_OK;  // an epoch over no interactions changes nothing
     MIREC_REQUIRE(if_indptr && if_indices && if_data && uf_indptr && uf_indices && uf_data && pos_indptr && user_ids &&
                       item_ids && y && order && item_emb && item_emb_grad && item_bias && item_bias_grad && user_emb &&
                       user_emb_grad && user_bias && user_bias_grad && ws,

@@ -110,3 +110,27 @@ def test_device_concurrent_epochs_reach_the_statements_auc():
     # the fitted model serves like a loaded one (hybrid_docker/inference.py:159-165)
     s = m.predict(3, np.arange(10, dtype=np.int32), user_features=p["user_features"], item_features=p["item_features"])
     assert s.shape == (10,) and np.isfinite(s).all()
+
+
+@pytest.mark.gpu
+def test_randomised_lightfm_parity_fixed_seed_and_empty_epoch():
+    """Fixed-seed slice of the randomised differential tool: 150 LightFM scoring / ranking cases and 100
+    serial WARP fits over random sizes, component counts, feature matrices, weights and penalties, all bit
+    for bit; an epoch over no interactions leaves the model as initialised."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for i in range(150):
+        ok, desc = fz.case_lightfm_eval(np.random.default_rng([21, i]))
+        assert ok, f"case {i}: {desc}"
+    for i in range(100):
+        ok, desc = fz.case_warp(np.random.default_rng([22, i]))
+        assert ok, f"case {i}: {desc}"
+    from movie_recommender_system_amd import LightFM
+    m = LightFM(no_components=4, loss="warp", random_state=1, learning_schedule="adagrad", serial=True)
+    m.fit_partial(sp.coo_matrix((5, 7), dtype=np.float32), epochs=1)
+    st = oracle.lightfm_init(5, 7, 4, 1)
+    assert all(np.array_equal(getattr(m, k), v) for k, v in st.items())

@@ -1,12 +1,14 @@
 """Randomised differential run of the device path against the CPU oracle (checker only).
 
-usage: python tools/fuzz_parity.py [--seconds 240] [--seed 1] [--kind topk|sweep|both] [--cases M] [--case N]
+usage: python tools/fuzz_parity.py [--seconds 240] [--seed 1] [--kind topk|sweep|both|lightfm|warp] [--cases M] [--case N]
 
 Draws shapes, widths, k, filters, value scales and tie patterns at random and compares
   top-K (both kernels)      ids and scores, bit for bit
   ALS half-sweep            relative Frobenius distance <= 2e-5 (the tolerance of the parity tests); beyond
                             it, every row within 20x the distance at which plain fp32 numpy CG lands from float64
   Gram                      1e-5 of the largest entry, symmetric bit for bit
+  LightFM (--kind lightfm)  representations, predict, recommend, predict_rank: bit for bit
+  WARP    (--kind warp)     serial epochs: parameters and adagrad accumulators bit for bit
 until the time is up.  Prints one line per failing case and a summary; exit status 1 if anything failed.
 Case N of a seed has a random stream of its own: `--case N` replays that case alone and shows where it differs.  Sizes are kept to what the oracle answers in well under a second.
 """
@@ -194,12 +196,126 @@ def case_sweep(rng):
     return ok, desc
 
 
+def rand_features(rng, rows, nfeat, identity_first):
+    """Random CSR feature matrix [rows, nfeat]: optional identity block, a few tokens per row (some rows
+    empty, some weights not 1)."""
+    dens = float(rng.choice([0.0, 2.0 / max(nfeat, 1), 0.2, 1.0]))
+    m = sp.random(rows, nfeat, density=min(dens, 1.0), random_state=np.random.RandomState(int(rng.integers(1 << 30))),
+                  format="lil", dtype=np.float32)
+    if identity_first:
+        for r in range(min(rows, nfeat)):
+            m[r, r] = 1.0
+    m = sp.csr_matrix(m)
+    if rng.random() < 0.5:
+        m.data[:] = 1.0
+    else:
+        m.data[:] = rng.uniform(0.1, 2.0, size=m.nnz).astype(np.float32)
+    m.sort_indices()
+    return m
+
+
+def case_lightfm_eval(rng):
+    from movie_recommender_system_amd import LightFMScorer
+    nu = int(rng.choice([1, 2, 63, 64, 65, int(rng.integers(1, 300))]))
+    ni = int(rng.choice([1, 2, 31, 64, 65, 129, int(rng.integers(1, 700))]))
+    nc = int(rng.choice([1, 2, 5, 10, 14, 15, 16, 30, 32, 62, 64]))
+    nuf, nif = nu + int(rng.integers(0, 30)), ni + int(rng.integers(0, 50))
+    uf, itf = rand_features(rng, nu, nuf, True), rand_features(rng, ni, nif, True)
+    coarse = rng.random() < 0.4   # integer-valued tables: many equal scores
+    tab = lambda *shape: (np.round(rng.standard_normal(shape)) if coarse else rng.standard_normal(shape) * 0.3).astype(np.float32)
+    ue, ub, ie, ib = tab(nuf, nc), tab(nuf), tab(nif, nc), tab(nif)
+    k = int(rng.choice([1, 5, 20, 24, 25, 50, int(rng.integers(1, 100))]))
+    desc = f"lightfm-eval nu={nu} ni={ni} nc={nc} nuf={nuf} nif={nif} coarse={coarse} k={k}"
+    sc = LightFMScorer(ue, ub, ie, ib)
+    ur, ir = oracle.lightfm_repr(uf, ue, ub), oracle.lightfm_repr(itf, ie, ib)
+    ok = True
+    gur, gir = sc.representations(uf, itf)
+    if not (np.array_equal(gur, ur) and np.array_equal(gir, ir)):
+        print(f"FAIL {desc}: representations differ", flush=True)
+        ok = False
+    npair = int(rng.integers(0, 500))
+    uids, iids = rng.integers(0, nu, npair).astype(np.int32), rng.integers(0, ni, npair).astype(np.int32)
+    if npair and not np.array_equal(sc.predict(uids, iids, item_features=itf, user_features=uf),
+                                    oracle.lightfm_predict(ur, ir, uids, iids)):
+        print(f"FAIL {desc}: predict differs", flush=True)
+        ok = False
+    ids, scores = sc.recommend(None, uf, itf, k)
+    oid, osc = oracle.lightfm_topk(ur, ir, k)
+    if not (np.array_equal(ids, oid) and np.array_equal(scores, osc)):
+        bad = np.nonzero((ids != oid).any(1) | (scores != osc).any(1))[0]
+        print(f"FAIL {desc}: recommend differs in {bad.size} rows, first {bad[:5].tolist()}", flush=True)
+        ok = False
+    inter = sp.random(nu, ni, density=float(rng.choice([0.0, 0.02, 0.3, 1.0])),
+                      random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csr", dtype=np.float32)
+    inter.data[:] = 1.0
+    held = rng.random(inter.nnz) < 0.4
+    coo = inter.tocoo()
+    test = sp.csr_matrix((coo.data[held], (coo.row[held], coo.col[held])), shape=inter.shape)
+    train = sp.csr_matrix((coo.data[~held], (coo.row[~held], coo.col[~held])), shape=inter.shape)
+    for tr in (train, None):
+        got = sc.predict_rank(test, tr, user_features=uf, item_features=itf)
+        want = oracle.lightfm_ranks(ur, ir, test, tr)
+        if not np.array_equal(got.data, want):
+            print(f"FAIL {desc}: ranks differ (train={'yes' if tr is not None else 'no'}) in "
+                  f"{int((got.data != want).sum())} of {test.nnz} entries", flush=True)
+            ok = False
+    return ok, desc
+
+
+def case_warp(rng):
+    from movie_recommender_system_amd import LightFM
+    nu = int(rng.choice([1, 2, 17, int(rng.integers(1, 120))]))
+    ni = int(rng.choice([2, 3, 17, int(rng.integers(2, 150))]))
+    nc = int(rng.choice([1, 2, 5, 10, 15, 16, 30, 32]))
+    nuf, nif = nu + int(rng.integers(0, 12)), ni + int(rng.integers(0, 20))
+    uf, itf = rand_features(rng, nu, nuf, True), rand_features(rng, ni, nif, True)
+    inter = sp.random(nu, ni, density=float(rng.choice([0.02, 0.1, 0.5, 0.95])),
+                      random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="coo", dtype=np.float32)
+    inter.data[:] = np.where(rng.random(inter.nnz) < 0.8, 1.0, rng.choice([-1.0, 0.5, 3.0], inter.nnz)).astype(np.float32)
+    item_alpha = float(rng.choice([0.0, 1e-6, 1e-3]))
+    user_alpha = float(rng.choice([0.0, 1e-5]))
+    max_sampled = int(rng.choice([1, 3, 10, 50]))
+    lr = float(rng.choice([0.05, 0.5]))
+    weights = rng.random() < 0.3
+    epochs = int(rng.integers(1, 3))
+    seed = int(rng.integers(1 << 30))
+    desc = (f"warp nu={nu} ni={ni} nc={nc} nuf={nuf} nif={nif} nnz={inter.nnz} ialpha={item_alpha} ualpha={user_alpha} "
+            f"max_sampled={max_sampled} lr={lr} weights={weights} epochs={epochs}")
+    sw = rng.uniform(0.2, 2.0, inter.nnz).astype(np.float32) if weights else None
+    rs = np.random.RandomState(seed)
+    st = oracle.lightfm_init(nuf, nif, nc, rs)
+    for _ in range(epochs):
+        order = np.arange(inter.nnz, dtype=np.int32)
+        rs.shuffle(order)
+        s = int(rs.randint(0, np.iinfo(np.int32).max))
+        oracle.lightfm_warp_epoch(st, inter, uf, itf, order, s, learning_rate=lr, item_alpha=item_alpha,
+                                  user_alpha=user_alpha, max_sampled=max_sampled, sample_weight=sw)
+    m = LightFM(no_components=nc, loss="warp", random_state=seed, learning_schedule="adagrad", learning_rate=lr,
+                item_alpha=item_alpha, user_alpha=user_alpha, max_sampled=max_sampled, serial=True)
+    swm = None if sw is None else sp.coo_matrix((sw, (inter.row, inter.col)), shape=inter.shape)
+    try:
+        for _ in range(epochs):
+            m.fit_partial(inter, user_features=uf, item_features=itf, sample_weight=swm, epochs=1)
+    except ValueError as e:   # "not all estimated parameters are finite": then the statement must have diverged too
+        if all(np.isfinite(v).all() for v in st.values()):
+            print(f"FAIL {desc}: device diverged, statement did not ({e})", flush=True)
+            return False, desc
+        return True, desc
+    ok = True
+    for name in st:
+        if not np.array_equal(getattr(m, name), st[name], equal_nan=True):
+            print(f"FAIL {desc}: {name} differs in {int((getattr(m, name) != st[name]).sum())} places", flush=True)
+            ok = False
+            break
+    return ok, desc
+
+
 def main():
     global VERBOSE
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--kind", choices=["topk", "sweep", "both"], default="both")
+    ap.add_argument("--kind", choices=["topk", "sweep", "both", "lightfm", "warp"], default="both")
     ap.add_argument("--case", type=int, default=-1)
     ap.add_argument("--cases", type=int, default=-1, help="stop after this many cases")
     args = ap.parse_args()
@@ -207,7 +323,7 @@ def main():
     def run_case(i):
         rng = np.random.default_rng([args.seed, i])
         kind = args.kind if args.kind != "both" else ("topk" if rng.random() < 0.4 else "sweep")
-        ok, desc = (case_topk if kind == "topk" else case_sweep)(rng)
+        ok, desc = {"topk": case_topk, "sweep": case_sweep, "lightfm": case_lightfm_eval, "warp": case_warp}[kind](rng)
         return kind, ok, f"case {i}: {desc}"
 
     if args.case >= 0:
@@ -216,7 +332,7 @@ def main():
         print(("ok   " if ok else "FAILED ") + desc)
         sys.exit(0 if ok else 1)
     t0 = time.time()
-    n = {"topk": 0, "sweep": 0}
+    n = {"topk": 0, "sweep": 0, "lightfm": 0, "warp": 0}
     fails = 0
     last = t0
     i = 0
