@@ -1,6 +1,6 @@
 """Randomised differential run of the device path against the CPU oracle (checker only).
 
-usage: python tools/fuzz_parity.py [--seconds 240] [--seed 1] [--kind topk|sweep|both|lightfm|warp] [--cases M] [--case N]
+usage: python tools/fuzz_parity.py [--seconds 240] [--seed 1] [--kind topk|sweep|both|lightfm|warp|data] [--cases M] [--case N]
 
 Draws shapes, widths, k, filters, value scales and tie patterns at random and compares
   top-K (both kernels)      ids and scores, bit for bit
@@ -9,6 +9,7 @@ Draws shapes, widths, k, filters, value scales and tie patterns at random and co
   Gram                      1e-5 of the largest entry, symmetric bit for bit
   LightFM (--kind lightfm)  representations, predict, recommend, predict_rank: bit for bit
   WARP    (--kind warp)     serial epochs: parameters and adagrad accumulators bit for bit
+  data    (--kind data)     CSR transpose, events -> CSR with item counts, ranking metrics: equal
 until the time is up.  Prints one line per failing case and a summary; exit status 1 if anything failed.
 Case N of a seed has a random stream of its own: `--case N` replays that case alone and shows where it differs.  Sizes are kept to what the oracle answers in well under a second.
 """
@@ -49,6 +50,8 @@ def rand_liked(rng, nq, ni, style):
 def case_topk(rng):
     nq = int(rng.choice([1, 2, 31, 32, 33, 127, 128, 129, int(rng.integers(1, 700))]))
     ni = int(rng.choice([1, 5, 31, 32, 33, 63, 64, 65, int(rng.integers(1, 6000)), int(rng.integers(1, 300))]))
+    if rng.random() < 0.03:     # long sweeps: the later points of the plane kernel's compaction schedule
+        ni, nq = int(rng.integers(6000, 30000)), min(nq, 130)
     f = int(rng.choice([1, 2, 3, 15, 16, 17, 32, 48, 64, 90, 96, 100, 128, 129, 160, 192, int(rng.integers(1, 193))]))
     k = int(rng.choice([1, 2, 5, 10, 20, 24, 25, 32, 64, 100, 224, int(rng.integers(1, 225))]))
     style = int(rng.integers(6))
@@ -73,10 +76,18 @@ def case_topk(rng):
     W = E.scoring_width(f, k) if rng.random() < 0.7 else E.factor_width(f, for_scoring=True)
     dQ, dY = E.pad_factors(Q, W, dev), E.pad_factors(Y, W, dev)
     mask = None if liked is None else E.DeviceCSR.from_scipy(liked, dev)
-    oid, osc = oracle.topk(Q, Y, k, liked=liked)
+    yn = qn = dyn = dqn = None
+    if rng.random() < 0.2:      # similar-items mode: scores divided by the norms of both sides
+        yn = (10.0 ** rng.uniform(-4, 2, ni)).astype(np.float32)
+        dyn = torch.from_numpy(yn).to(dev)
+        if rng.random() < 0.7:
+            qn = (10.0 ** rng.uniform(-4, 2, nq)).astype(np.float32)
+            dqn = torch.from_numpy(qn).to(dev)
+        desc += " norms=" + ("both" if qn is not None else "items")
+    oid, osc = oracle.topk(Q, Y, k, liked=liked, y_norm=yn, q_norm=qn)
     ok = True
     for ws in (True, False):
-        ids, sc = E.topk(dQ, dY, k, mask, None, None, workspace=ws)
+        ids, sc = E.topk(dQ, dY, k, mask, dyn, dqn, workspace=ws)
         ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
         if not (np.array_equal(ids, oid) and np.array_equal(sc, osc)):
             bad = np.nonzero((ids != oid).any(1) | (sc != osc).any(1))[0]
@@ -310,12 +321,55 @@ def case_warp(rng):
     return ok, desc
 
 
+def case_data(rng):
+    """Data-side kernels: CSR transpose, events -> CSR with item counts, ranking metrics."""
+    from movie_recommender_system_amd import evaluate
+    rows, cols = int(rng.choice([1, 2, 64, int(rng.integers(1, 1500))])), int(rng.choice([1, 3, 65, int(rng.integers(1, 900))]))
+    dens = float(rng.choice([0.0, 0.001, 0.05, 0.6, 1.0]))
+    desc = f"data rows={rows} cols={cols} dens={dens}"
+    ok = True
+    C = sp.random(rows, cols, density=dens, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csr",
+                  dtype=np.float32)
+    C.sort_indices()
+    T = E.DeviceCSR.from_scipy(C, dev).transpose().to_scipy()
+    ref = sp.csr_matrix(C.T)
+    ref.sort_indices()
+    if not (T.shape == ref.shape and np.array_equal(T.indptr, ref.indptr) and np.array_equal(T.indices, ref.indices)
+            and np.array_equal(T.data, ref.data)):
+        print(f"FAIL {desc}: transpose", flush=True)
+        ok = False
+    n_events = int(rng.choice([0, 1, 7, int(rng.integers(0, 60000))]))
+    u = rng.integers(0, rows, size=n_events).astype(np.int32)
+    mm = (rng.zipf(1.5, size=n_events) % cols).astype(np.int32)
+    csr, counts = E.DeviceCSR.from_events(torch.from_numpy(u).to(dev), torch.from_numpy(mm).to(dev), (rows, cols),
+                                          with_item_counts=True)
+    got = csr.to_scipy()
+    ref = sp.csr_matrix((np.ones(n_events, dtype=np.float32), (u, mm)), shape=(rows, cols))
+    ref.sum_duplicates()
+    ref.data[:] = 1.0
+    ref.sort_indices()
+    if not (got.nnz == ref.nnz and np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+            and np.all(got.data == 1.0)
+            and np.array_equal(counts.cpu().numpy(), np.asarray(ref.sum(axis=0)).ravel().astype(np.int32))):
+        print(f"FAIL {desc}: events -> CSR (n_events={n_events})", flush=True)
+        ok = False
+    k = int(rng.choice([1, 5, 20, 50]))
+    rec = rng.integers(0, cols, size=(rows, k)).astype(np.int32)
+    rec[rng.random((rows, k)) < 0.1] = -1
+    want = als_numpy.ranking_metrics(rec, C, k)
+    have = evaluate.ranking_metrics(rec, C, k, device=dev)
+    if any(have[key] != want[key] for key in ("precision", "recall", "f1", "hit_rate", "users")):
+        print(f"FAIL {desc}: ranking metrics k={k}: {have} vs {want}", flush=True)
+        ok = False
+    return ok, desc
+
+
 def main():
     global VERBOSE
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--kind", choices=["topk", "sweep", "both", "lightfm", "warp"], default="both")
+    ap.add_argument("--kind", choices=["topk", "sweep", "both", "lightfm", "warp", "data"], default="both")
     ap.add_argument("--case", type=int, default=-1)
     ap.add_argument("--cases", type=int, default=-1, help="stop after this many cases")
     args = ap.parse_args()
@@ -323,7 +377,7 @@ def main():
     def run_case(i):
         rng = np.random.default_rng([args.seed, i])
         kind = args.kind if args.kind != "both" else ("topk" if rng.random() < 0.4 else "sweep")
-        ok, desc = {"topk": case_topk, "sweep": case_sweep, "lightfm": case_lightfm_eval, "warp": case_warp}[kind](rng)
+        ok, desc = {"topk": case_topk, "sweep": case_sweep, "lightfm": case_lightfm_eval, "warp": case_warp, "data": case_data}[kind](rng)
         return kind, ok, f"case {i}: {desc}"
 
     if args.case >= 0:
@@ -332,7 +386,7 @@ def main():
         print(("ok   " if ok else "FAILED ") + desc)
         sys.exit(0 if ok else 1)
     t0 = time.time()
-    n = {"topk": 0, "sweep": 0, "lightfm": 0, "warp": 0}
+    n = {"topk": 0, "sweep": 0, "lightfm": 0, "warp": 0, "data": 0}
     fails = 0
     last = t0
     i = 0
