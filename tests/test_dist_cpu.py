@@ -66,21 +66,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, nu=300, ni=90, blocks=3, deg=10.0):
     import oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        M = synth.interactions(3, 300, 90, 10.0)
+        M = synth.interactions(3, nu, ni, deg)
         Cui = sp.csr_matrix(M * np.float32(40.0))
         Ciu = sp.csr_matrix(Cui.T)
-        X0, Y0 = oracle.oracle.init_factors(300, 90, 16, 42)
-        users = D.BlockCyclic(300, world, blocks=3)
+        X0, Y0 = oracle.oracle.init_factors(nu, ni, 16, 42)
+        users = D.BlockCyclic(nu, world, blocks=blocks)
         Xpad = torch.zeros((users.padded, 16), dtype=torch.float32)
-        Xpad[:300] = torch.from_numpy(X0)
+        Xpad[:nu] = torch.from_numpy(X0)
         Y = torch.from_numpy(Y0.copy())
-        Xn, Yn = Xpad[:300].numpy(), Y.numpy()   # views: the oracle updates the tensors in place
+        Xn, Yn = Xpad[:nu].numpy(), Y.numpy()   # views: the oracle updates the tensors in place
         ib = D.partition_rows(Ciu.indptr, world)
         drv = D.ShardedAlsDriver(
             Xpad, Y, users, ib,
@@ -107,3 +107,18 @@ def test_two_ranks_equal_single_process(tmp_path):
     for r in (r0, r1):
         assert np.array_equal(r["X"], Xr)
         assert np.array_equal(r["Y"], Yr)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,nu,ni,blocks", [(3, 5, 2, 2), (4, 37, 9, 1), (3, 100, 40, 4)])
+def test_odd_worlds_and_shards_without_rows(tmp_path, world, nu, ni, blocks):
+    """More ranks than items, blocks without users, a world size that divides nothing: every rank still ends
+    with the factors of the single-process fit, bit for bit."""
+    import oracle
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nu, ni, blocks, 3.0), nprocs=world, join=True)
+    M = synth.interactions(3, nu, ni, 3.0)
+    Xr, Yr = oracle.als_fit(M, factors=16, regularization=0.01, alpha=40.0, iterations=3, random_state=42)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(got["X"], Xr), r
+        assert np.array_equal(got["Y"], Yr), r
