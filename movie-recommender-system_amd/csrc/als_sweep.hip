@@ -933,6 +933,7 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
                                     int32_t short_max, const int64_t host_counts[4], void* ws, size_t ws_bytes,
                                     mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (row_end == row_begin) return MIREC_OK;  // a shard without rows (its X block may be a null pointer)
     MIREC_REQUIRE(indptr && X && Y && G && plan && host_counts, MIREC_E_INVALID, "mirec_als_half_sweep: null argument");
     MIREC_REQUIRE(nnz == 0 || (indices && data), MIREC_E_INVALID, "mirec_als_half_sweep: null indices/data");
     MIREC_REQUIRE(row_end >= row_begin && cg_steps >= 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad range or cg_steps");

@@ -169,14 +169,12 @@ def gpu_driver(Cui, Ciu, X: torch.Tensor, Y: torch.Tensor, regularization: float
     ib = partition_rows(Ciu.indptr, world)
     eng = E.AlsEngine(Cui, Ciu, Xpad[:users.nrows], Y, regularization, cg_steps, user_blocks=users.owned(rank),
                       item_rows=(ib[rank], ib[rank + 1]), chunk_nnz=chunk_nnz, short_max=short_max)
-    started = {"n": 0}
+    # The driver walks this rank's blocks in order and skips those without rows; block 0 (which refreshes the
+    # Gram of Y) is empty only if all of the rank's blocks are, since later slabs hold higher rows.
+    index_of = {blk: j for j, blk in enumerate(eng.user_blocks) if blk[1] > blk[0]}
 
     def solve_users(a, b):
-        # the driver walks this rank's blocks in order; the Gram of Y is refreshed before the first of them
-        j = started["n"] % len(eng.user_blocks)
-        started["n"] += 1
-        assert eng.user_blocks[j] == (a, b)
-        eng.user_sweep_block(j)
+        eng.user_sweep_block(index_of[(a, b)])
 
     drv = ShardedAlsDriver(Xpad, Y, users, ib, solve_users, lambda a, b: eng.item_sweep(), rank, group)
     return drv, eng

@@ -204,3 +204,27 @@ def test_alpha_applied_once_or_prescaled(dev):
     assert rel(b.user_factors, Xb) < 1e-3 and rel(b.item_factors, Yb) < 1e-3
     assert rel(b.user_factors, Xb64) < 1.5 * rel(Xb, Xb64) + 1e-4
     assert rel(b.item_factors, Yb64) < 1.5 * rel(Yb, Yb64) + 1e-4
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,users,items", [(3, 50, 7), (4, 1000, 3)])
+def test_sharded_driver_with_shards_without_rows(dev, world, users, items):
+    """The sharded device driver on `world` ranks that share this one GPU (gloo, collectives staged through the
+    host: tools/rehearse_check.py) where some ranks own no user block or no item at all: factors equal the
+    one-rank run bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, REHEARSE_USERS=str(users), REHEARSE_ITEMS=str(items))
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "tools", "rehearse_check.py")], env=env, capture_output=True, text=True,
+                         timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "factors bit-identical: True" in res.stdout

@@ -1,6 +1,7 @@
 """Two ranks on one GPU (gloo, host-staged collectives as in tools/rehearse_multi_rank.py): the factors after two
 sharded iterations must equal, bit for bit, those of a one-rank run of the same problem.  Launch with
-torch.distributed.run --nproc-per-node 2."""
+torch.distributed.run --nproc-per-node 2.  REHEARSE_USERS / REHEARSE_ITEMS override the problem size (small ones
+leave ranks and blocks without rows)."""
 import os
 import sys
 
@@ -40,7 +41,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-U, I, f = 60_000, 5_000, 128
+U, I, f = int(os.environ.get("REHEARSE_USERS", 60_000)), int(os.environ.get("REHEARSE_ITEMS", 5_000)), 128
 indptr, indices, data = synth.interactions_torch(7, U, I, 40.0, dev)
 Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
 Ciu = Cui.transpose()
