@@ -380,15 +380,18 @@ static int launch_short(const int64_t* indptr, const int32_t* indices, const flo
                         hipStream_t stream) {
     using L = ShortLds<NT>;
     constexpr int SW = L::SW;
-    static bool attr_done = false;  // idempotent; a race only repeats the call
-    static int cus = 0;
-    if (!attr_done) {
+    static OncePerDevice once;  // idempotent; a race only repeats the call
+    static int cus_of[kMaxDevices] = {};
+    bool* attr_done = once.slot();
+    MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
+    int& cus = cus_of[attr_done - once.done];
+    if (!*attr_done) {
         MIREC_HIP(hipFuncSetAttribute((const void*)als_short_kernel<NT, BIG>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
         int dev = 0;
         MIREC_HIP(hipGetDevice(&dev));
         MIREC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done = true;
+        *attr_done = true;
     }
     int64_t blocks = (nrows + SW - 1) / SW;
     if (blocks > cus) blocks = cus;

@@ -811,15 +811,17 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
     const int32_t* mslot_ptr = (const int32_t*)(plan + L.mslot_ptr);
     const int32_t* chunk_row = (const int32_t*)(plan + L.chunk_row);
     const int32_t* multi_row = (const int32_t*)(plan + L.multi_row);
-    static bool attr_done = false;  // idempotent; a race only repeats the call
-    if (!attr_done) {
+    static OncePerDevice once;  // idempotent; a race only repeats the call
+    bool* attr_done = once.slot();
+    MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
+    if (!*attr_done) {
         MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
         MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
         MIREC_HIP(hipFuncSetAttribute((const void*)als_finalize_kernel<NT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
-        attr_done = true;
+        *attr_done = true;
     }
     if (counts[0] > 0) {
         // byte offsets into the gathered table are kept in 32 bits while the whole table is addressable that way

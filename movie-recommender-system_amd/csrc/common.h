@@ -46,6 +46,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 
+// Kernel attributes (dynamic LDS size) are set once per device: a process may drive several GPUs.
+constexpr int kMaxDevices = 64;
+struct OncePerDevice {
+    bool done[kMaxDevices] = {};
+    // Slot of the current device, or nullptr if its ordinal is out of range / cannot be read.
+    bool* slot() {
+        int d = -1;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
+        return &done[d];
+    }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

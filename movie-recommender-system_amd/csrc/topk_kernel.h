@@ -347,11 +347,13 @@ static int launch_topk_cfg(const float* Q, int64_t nq, const float* Y, int64_t n
                            int32_t* out_ids, float* out_scores, const int32_t* qlist, const int32_t* qcount,
                            hipStream_t stream) {
     using L = TopkLds<F, WAVES, CAP>;
-    static bool attr_done = false;  // idempotent; a race only repeats the call
-    if (!attr_done) {
+    static OncePerDevice once;  // idempotent; a race only repeats the call
+    bool* attr_done = once.slot();
+    MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
+    if (!*attr_done) {
         MIREC_HIP(hipFuncSetAttribute((const void*)topk_kernel<F, WAVES, CAP>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
-        attr_done = true;
+        *attr_done = true;
     }
     const int64_t blocks = (nq + 32 * WAVES - 1) / (32 * WAVES);
     hipLaunchKernelGGL((topk_kernel<F, WAVES, CAP>), dim3((unsigned)blocks), dim3(64 * WAVES), L::BYTES, stream, Q, nq,

@@ -860,11 +860,13 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
                                   hipStream_t stream) {
     using L = TopkPlanesLds<F, WM, CAP>;
     static_assert(L::BYTES <= 160 * 1024, "top-K plane kernel: LDS image too large");
-    static bool attr_done = false;  // idempotent; a race only repeats the call
-    if (!attr_done) {
+    static OncePerDevice once;  // idempotent; a race only repeats the call
+    bool* attr_done = once.slot();
+    MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
+    if (!*attr_done) {
         MIREC_HIP(hipFuncSetAttribute((const void*)topk_planes_kernel<F, WM, CAP>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
-        attr_done = true;
+        *attr_done = true;
     }
     const TopkWorkspace lay = topk_workspace_layout(nq, ni, F);
     char* base = static_cast<char*>(ws);
