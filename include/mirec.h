@@ -86,7 +86,9 @@ int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, 
  *               kernel}
  * mirec_als_plan_build synchronises `stream` before it returns.  The sweep
  * takes the plan, `chunk_nnz` and `host_counts` exactly as the build left them
- * and a workspace of mirec_als_sweep_workspace_bytes(host_counts, f) bytes. */
+ * and a workspace of mirec_als_sweep_workspace_bytes(host_counts, f) bytes.
+ * A sweep over an empty row range (row_begin == row_end: a shard that owns no
+ * rows) returns MIREC_OK without reading any other argument. */
 int mirec_als_short_cache_rows(int f);
 size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk_nnz);
 int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_end, int64_t nnz, int f,
@@ -189,7 +191,8 @@ int mirec_lightfm_ranks(const float* urepr, const float* irepr, int64_t nu, int6
  * them one after the other in `order` (the sequential statement, for checking).
  * Negatives are drawn from a counter-based generator keyed by (seed, example).
  * ws: device scratch of mirec_lightfm_warp_workspace_bytes(max_sampled) bytes.
- * The call synchronises the stream once (it uploads a small table). */
+ * The call synchronises the stream once (it uploads a small table).
+ * n_examples == 0 is a valid epoch that changes nothing. */
 size_t mirec_lightfm_warp_workspace_bytes(int max_sampled);
 int mirec_lightfm_warp_epoch(
     const int64_t* if_indptr, const int32_t* if_indices, const float* if_data, int64_t n_items, int64_t n_item_features,
