@@ -228,3 +228,70 @@ def test_sharded_driver_with_shards_without_rows(dev, world, users, items):
                          timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "factors bit-identical: True" in res.stdout
+
+
+@pytest.mark.timeout(600)
+def test_full_size_sweeps_on_sampled_rows_and_loss(dev):
+    """The benchmark's configuration (1 M users x 27 k items, ~48 M interactions, f = 128): after each
+    half-sweep of a device iteration a sample of the solved rows (short and long ones, the longest included)
+    is solved again by the oracle from the same inputs and must agree to the half-sweep tolerance; the run is
+    reproducible bit for bit; the regularised implicit-feedback loss goes down from iteration to iteration."""
+    import torch
+    from movie_recommender_system_amd import engine as E, synth
+    U, I, f, reg = 1_000_000, 27_000, 128, 0.01
+    indptr, indices, data = synth.interactions_torch(42, U, I, 50.0, dev)
+    Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
+    Ciu = Cui.transpose()
+    rs = np.random.RandomState(42)
+    X0 = torch.from_numpy(rs.rand(U, f).astype(np.float32) * 0.01).to(dev)
+    Y0 = torch.from_numpy(rs.rand(I, f).astype(np.float32) * 0.01).to(dev)
+    rng = np.random.default_rng(0)
+
+    def sample_rows(csr, count):
+        ptr = csr.indptr.cpu().numpy()
+        ln = np.diff(ptr)
+        pick = np.unique(np.r_[rng.integers(0, csr.shape[0], count), np.argsort(ln)[-4:], np.argsort(ln)[:2]])
+        idx = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in pick]) if len(pick) else np.zeros(0, np.int64)
+        t = torch.from_numpy(idx).to(dev)
+        sub = sp.csr_matrix((csr.data[t].cpu().numpy(), csr.indices[t].cpu().numpy(), np.r_[0, np.cumsum(ln[pick])]),
+                            shape=(len(pick), csr.shape[1]))
+        return pick, sub
+
+    def check_side(csr, solved_before, solved_after, other, G, count):
+        pick, sub = sample_rows(csr, count)
+        t = torch.from_numpy(pick).to(dev)
+        want = solved_before[t].cpu().numpy().copy()
+        oracle.als_half_sweep(sub, want, other.cpu().numpy(), reg, 3, YtY=G.cpu().numpy())
+        got = solved_after[t].cpu().numpy()
+        if rel(got, want) < 2e-5:
+            return
+        # From the benchmark's start (factors of size 0.01) the first systems are dominated by reg*I and three CG
+        # steps leave an iterate that moves with the rounding inside the steps; the float64 statement of the same
+        # steps arbitrates: the device may not be further from it than 1.5 x the fp32 oracle is.
+        from oracle import als_numpy
+        ref = als_numpy.half_sweep_f64(sub, solved_before[t].cpu().numpy(), other.cpu().numpy(), reg, 3)
+        d_dev, d_orc = rel(got, ref), rel(want, ref)
+        print(f"sampled rows: device-oracle {rel(got, want):.2e}, device-float64 {d_dev:.2e}, oracle-float64 {d_orc:.2e}")
+        assert d_dev < 1.5 * d_orc + 2e-5, (d_dev, d_orc)
+
+    def iteration(X, Y):
+        eng = E.AlsEngine(Cui, Ciu, X, Y, reg, 3)
+        Xb = X.clone()
+        eng.user_sweep()
+        check_side(Cui, Xb, X, Y, eng.G, 1500)
+        Yb = Y.clone()
+        eng.item_sweep()
+        check_side(Ciu, Yb, Y, X, eng.G, 60)
+
+    X, Y = X0.clone(), Y0.clone()
+    host_C = sp.csr_matrix((Cui.data.cpu().numpy(), Cui.indices.cpu().numpy(), Cui.indptr.cpu().numpy()), shape=(U, I))
+    losses = [oracle.als_loss(host_C, X.cpu().numpy(), Y.cpu().numpy(), reg)]
+    for _ in range(2):
+        iteration(X, Y)
+        losses.append(oracle.als_loss(host_C, X.cpu().numpy(), Y.cpu().numpy(), reg))
+    assert losses[2] < losses[1] < losses[0], losses
+    X2, Y2 = X0.clone(), Y0.clone()
+    eng = E.AlsEngine(Cui, Ciu, X2, Y2, reg, 3)
+    for _ in range(2):
+        eng.iteration()
+    assert torch.equal(X2, X) and torch.equal(Y2, Y)
