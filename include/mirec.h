@@ -187,8 +187,11 @@ int mirec_lightfm_ranks(const float* urepr, const float* irepr, int64_t nu, int6
  * with y[e] > 0, visited in `order`; sample_weight may be null (ones).
  * Parameters and their squared-gradient accumulators (initially one) are updated
  * in place; no_components <= 63.  Examples run concurrently and update shared
- * parameters without locks, as the library's OpenMP threads do; serial != 0 runs
- * them one after the other in `order` (the sequential statement, for checking).
+ * parameters without locks, as the library's OpenMP threads do -- in phases:
+ * one workgroup at first, then as many examples side by side as 1/256 of those
+ * the call has already worked through (more at the start, where every
+ * accumulator is one, keeps the model from learning); serial != 0 runs them one
+ * after the other in `order` (the sequential statement, for checking).
  * Negatives are drawn from a counter-based generator keyed by (seed, example).
  * ws: device scratch of mirec_lightfm_warp_workspace_bytes(max_sampled) bytes.
  * The call synchronises the stream once (it uploads a small table).

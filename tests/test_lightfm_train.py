@@ -134,3 +134,26 @@ def test_randomised_lightfm_parity_fixed_seed_and_empty_epoch():
     m.fit_partial(sp.coo_matrix((5, 7), dtype=np.float32), epochs=1)
     st = oracle.lightfm_init(5, 7, 4, 1)
     assert all(np.array_equal(getattr(m, k), v) for k, v in st.items())
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_concurrent_epochs_keep_learning_at_scale():
+    """10 k users x 1.5 k items, 0.2 M examples: thousands of examples in flight from the first one on learn
+    next to nothing (every adagrad accumulator starts at one and the feature rows all users share take thousands
+    of full-size steps at once); the phased schedule of the device epoch must stay within 0.02 of the serial
+    mode's held-out AUC after three epochs."""
+    import torch
+    assert torch.cuda.is_available()
+    from movie_recommender_system_amd import LightFM
+    from movie_recommender_system_amd.lightfm import auc_score
+    p, train, test = planted(seed=1, nu=10000, ni=1500, clusters=20, per_user=25)
+    tr = sp.csr_matrix(train)
+    aucs = {}
+    for serial in (False, True):
+        m = LightFM(no_components=15, loss="warp", random_state=42, learning_schedule="adagrad", item_alpha=1e-6,
+                    serial=serial)
+        m.fit_partial(train, user_features=p["user_features"], item_features=p["item_features"], epochs=3)
+        aucs[serial] = float(auc_score(m, test, tr, user_features=p["user_features"],
+                                       item_features=p["item_features"]).mean())
+    assert aucs[True] > 0.85 and abs(aucs[False] - aucs[True]) < 0.02, aucs
