@@ -190,8 +190,11 @@ int mirec_lightfm_ranks(const float* urepr, const float* irepr, int64_t nu, int6
  * parameters without locks, as the library's OpenMP threads do -- in phases:
  * one workgroup at first, then as many examples side by side as 1/256 of those
  * the call has already worked through (more at the start, where every
- * accumulator is one, keeps the model from learning); serial != 0 runs them one
- * after the other in `order` (the sequential statement, for checking).
+ * accumulator is one, keeps the model from learning).  examples_seen: how many
+ * examples the model has worked through in earlier calls (0 for a fresh model,
+ * or when not known: the call then starts again at one workgroup); they count
+ * like the call's own.  serial != 0 runs the examples one after the other in
+ * `order` (the sequential statement, for checking).
  * Negatives are drawn from a counter-based generator keyed by (seed, example).
  * ws: device scratch of mirec_lightfm_warp_workspace_bytes(max_sampled) bytes.
  * The call synchronises the stream once (it uploads a small table).
@@ -204,7 +207,7 @@ int mirec_lightfm_warp_epoch(
     const float* y, const float* sample_weight, const int32_t* order, int64_t n_examples, float* item_emb,
     float* item_emb_grad, float* item_bias, float* item_bias_grad, float* user_emb, float* user_emb_grad,
     float* user_bias, float* user_bias_grad, int nc, double learning_rate, double item_alpha, double user_alpha,
-    int max_sampled, uint32_t seed, int serial, void* ws, size_t ws_bytes, mirec_stream_t stream);
+    int max_sampled, uint32_t seed, int serial, int64_t examples_seen, void* ws, size_t ws_bytes, mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Held-out ranking evaluation over the top-k output (the evaluation cell of

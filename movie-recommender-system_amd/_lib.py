@@ -42,7 +42,7 @@ SIGNATURES = {
     "mirec_lightfm_warp_workspace_bytes": (_sz, [_int]),
     "mirec_lightfm_warp_epoch": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_double, _c.c_double,
-                                        _c.c_double, _int, _c.c_uint32, _int, _vp, _sz, _vp]),
+                                        _c.c_double, _int, _c.c_uint32, _int, _i64, _vp, _sz, _vp]),
     "mirec_lightfm_ranks": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mirec_topk_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mirec_topk": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _sz, _vp]),

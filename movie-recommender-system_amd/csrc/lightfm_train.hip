@@ -227,12 +227,14 @@ extern "C" int mirec_lightfm_warp_epoch(
     const float* y, const float* sample_weight, const int32_t* order, int64_t n_examples, float* item_emb,
     float* item_emb_grad, float* item_bias, float* item_bias_grad, float* user_emb, float* user_emb_grad,
     float* user_bias, float* user_bias_grad, int nc, double learning_rate, double item_alpha, double user_alpha,
-    int max_sampled, uint32_t seed, int serial, void* ws, size_t ws_bytes, mirec_stream_t stream_) {
+    int max_sampled, uint32_t seed, int serial, int64_t examples_seen, void* ws, size_t ws_bytes,
+    mirec_stream_t stream_) {
     using namespace mirec;
     hipStream_t stream = (hipStream_t)stream_;
     MIREC_REQUIRE(nc >= 1 && nc <= 63, MIREC_E_UNSUPPORTED, "mirec_lightfm_warp_epoch: no_components must be 1..63 (got %d)", nc);
     MIREC_REQUIRE(n_items >= 1 && n_items < ((int64_t)1 << 31) && n_examples >= 0 && max_sampled >= 1, MIREC_E_INVALID,
                   "mirec_lightfm_warp_epoch: bad sizes");
+    MIREC_REQUIRE(examples_seen >= 0, MIREC_E_INVALID, "mirec_lightfm_warp_epoch: examples_seen must be >= 0");
     if (n_examples == 0) return MIREC_OK;  // an epoch over no interactions changes nothing
     MIREC_REQUIRE(if_indptr && if_indices && if_data && uf_indptr && uf_indices && uf_data && pos_indptr && user_ids &&
                       item_ids && y && order && item_emb && item_emb_grad && item_bias && item_bias_grad && user_emb &&
@@ -262,8 +264,9 @@ extern "C" int mirec_lightfm_warp_epoch(
         // concurrent examples add to it, i.e. when the examples in flight are few against the examples already
         // worked through -- and ruinous at the start, where every accumulator is one and thousands of full-size
         // steps would land on the rows that all examples share.  So the epoch runs in phases: one workgroup for
-        // the first examples, then as many groups as a KAPPA-th of the examples this call has completed, the
-        // phase length doubling with it (each phase costs about KAPPA examples' time, whatever its size).
+        // the first examples of a fresh model, then as many groups as a KAPPA-th of the examples the model has
+        // worked through (in earlier calls, as the caller reports them, and in this one), the phase length
+        // doubling with it (each phase costs about KAPPA examples' time, whatever its size).
         // Measured on planted-cluster problems (tools/probes/warp_quality.py; held-out AUC after 1 / 3 epochs):
         // 20 k users x 2 k items, 0.4 M examples -- sequential 0.692 / 0.906; all examples in flight at n/64
         // groups (the first version of this function) 0.522 / 0.664; KAPPA 64 0.677 / 0.907 in 0.09 s per epoch,
@@ -278,10 +281,11 @@ extern "C" int mirec_lightfm_warp_epoch(
             int blocks = 1, threads = serial ? G : 256;
             int64_t len = n_examples;
             if (!serial) {
-                int64_t nb = done / kappa / per_block;
+                const int64_t seen = examples_seen + done;
+                int64_t nb = seen / kappa / per_block;
                 nb = nb < 1 ? 1 : (nb < cap ? nb : cap);
                 blocks = (int)nb;
-                len = nb >= cap ? n_examples - done : (done == 0 ? per_block * kappa : done);
+                len = nb >= cap ? n_examples - done : (seen < per_block * kappa ? per_block * kappa : seen);
                 if (len > n_examples - done) len = n_examples - done;
             }
             const int32_t* ord = order + done;

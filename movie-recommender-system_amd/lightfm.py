@@ -231,6 +231,7 @@ class LightFM(LightFMScorer):
         self.serial = bool(serial)
         self.item_embedding_gradients = self.item_bias_gradients = None
         self.user_embedding_gradients = self.user_bias_gradients = None
+        self._examples_seen = 0
 
     def _initialize(self, no_user_features: int, no_item_features: int) -> None:
         # lightfm.LightFM._initialize: items first, then users; adagrad accumulators start at one
@@ -244,6 +245,7 @@ class LightFM(LightFMScorer):
         self.user_embedding_gradients = np.ones((no_user_features, nc), dtype=np.float32)
         self.user_biases = np.zeros(no_user_features, dtype=np.float32)
         self.user_bias_gradients = np.ones(no_user_features, dtype=np.float32)
+        self._examples_seen = 0   # what the accumulators have absorbed: sets how many examples may run side by side
 
     def fit(self, interactions, user_features=None, item_features=None, sample_weight=None, epochs: int = 1,
             num_threads: int = 1, verbose: bool = False):
@@ -305,7 +307,9 @@ class LightFM(LightFMScorer):
                     E._ptr(par["item_bias_gradients"]), E._ptr(par["user_embeddings"]),
                     E._ptr(par["user_embedding_gradients"]), E._ptr(par["user_biases"]), E._ptr(par["user_bias_gradients"]),
                     nc, self.learning_rate, self.item_alpha, self.user_alpha, self.max_sampled, seed,
-                    1 if self.serial else 0, E._ptr(ws), ws_bytes, E._stream_ptr()), "mirec_lightfm_warp_epoch")
+                    1 if self.serial else 0, self._examples_seen, E._ptr(ws), ws_bytes, E._stream_ptr()),
+                    "mirec_lightfm_warp_epoch")
+                self._examples_seen += int(coo.nnz)
             for n in names:
                 setattr(self, n, par[n].cpu().numpy())
             self._dev = {}  # the scorer's device tables are stale
