@@ -51,6 +51,20 @@ class LightFMScorer:
         self._lock = threading.Lock()
         self._dev = {}
 
+    # ------------------------------------------------------------------- state
+    # The reference stores and reloads the whole model object (joblib.dump / joblib.load at
+    # hybrid_docker/train.py:182 and hybrid_docker/inference.py:102): everything but the lock and the device
+    # copies of the tables is plain data.
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in ("_lock", "_dev")}
+        state["device"] = None if self.device is None else str(self.device)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._lock = threading.Lock()
+        self._dev = {}
+
     # ----------------------------------------------------------------- helpers
     def _tables(self, dev):
         if self._dev.get("device") != dev:

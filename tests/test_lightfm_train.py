@@ -157,3 +157,26 @@ def test_concurrent_epochs_keep_learning_at_scale():
         aucs[serial] = float(auc_score(m, test, tr, user_features=p["user_features"],
                                        item_features=p["item_features"]).mean())
     assert aucs[True] > 0.85 and abs(aucs[False] - aucs[True]) < 0.02, aucs
+
+
+def test_model_object_round_trips_through_joblib(tmp_path):
+    """hybrid_docker/train.py:182 dumps the model object with joblib and hybrid_docker/inference.py:102 loads it
+    again: parameters, accumulators, hyper-parameters and the random state survive; the lock and the device
+    tables are rebuilt."""
+    import joblib
+    from movie_recommender_system_amd import LightFM, LightFMScorer
+    m = LightFM(no_components=6, loss="warp", random_state=7, learning_schedule="adagrad", item_alpha=1e-6)
+    m._initialize(9, 11)
+    m._examples_seen = 1234
+    path = tmp_path / "lightfm_model.joblib"
+    joblib.dump(m, path)
+    r = joblib.load(path)
+    for name in ("item_embeddings", "item_biases", "user_embeddings", "user_biases", "item_embedding_gradients",
+                 "item_bias_gradients", "user_embedding_gradients", "user_bias_gradients"):
+        assert np.array_equal(getattr(r, name), getattr(m, name)), name
+    assert (r.no_components, r.item_alpha, r.max_sampled, r.learning_rate, r._examples_seen) == (6, 1e-6, 10, 0.05, 1234)
+    assert r.random_state.randint(1 << 30) == m.random_state.randint(1 << 30)
+    assert r._lock is not m._lock and r._dev == {}
+    sc = LightFMScorer(m.user_embeddings, m.user_biases, m.item_embeddings, m.item_biases)
+    joblib.dump(sc, path)
+    assert np.array_equal(joblib.load(path).item_embeddings, m.item_embeddings)
