@@ -46,5 +46,6 @@ shutil.move(os.path.join(prof, f"{prev}_l2_hit_rates.json"), os.path.join(prof, 
 for f in glob.glob(os.path.join(prof, f"{prev}_*")):
     os.remove(f)
 p = os.path.join(root, "DESIGN.md")
-open(p, "w").write(open(p).read().replace(prev + "_", tag + "_"))
+text = open(p).read()   # (read before the file is opened for writing)
+open(p, "w").write(text.replace(prev + "_", tag + "_"))
 print(out[:1800])
