@@ -2,8 +2,8 @@
 
 usage: python tools/install_profile.py <tag> <previous tag> "<one-line description of the capture>"
 Writes profiles/<tag>_bench_kernel_stats.{md,csv}, _bench_line.json, _pmc_traffic.json; carries the notes below
-the table and the L2 counter file over from the previous tag, removes the previous tag's files and points
-DESIGN.md at the new ones.
+the table and the L2 counter file over from the previous tag, removes the previous tag's files and renames the
+references to them in the design notes at the repository root.
 """
 import csv
 import glob
@@ -20,7 +20,7 @@ prof = os.path.join(root, "profiles")
 old = open(os.path.join(prof, f"{prev}_bench_kernel_stats.md")).read()
 rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
 head = old.split("| kernel |")[0].replace(prev, tag)
-head = re.sub(r"^# .*$", f"# rocprofv3 --kernel-trace --stats, round 1, {what}", head, count=1, flags=re.M)
+head = re.sub(r"^# .*$", f"# rocprofv3 --kernel-trace --stats, {what}", head, count=1, flags=re.M)
 name = lambda n: re.sub(r"\(.*$", "", re.sub(r"^void ", "", n))
 out = head + "| kernel | calls | avg ms | max ms | total ms | % |\n|---|---|---|---|---|---|\n"
 for r in rows[:24]:
