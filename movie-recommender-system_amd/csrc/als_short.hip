@@ -17,7 +17,10 @@
 // loads at F = 128: lane c owns columns [c*NT, c*NT+NT)), GV rows each per
 // step; their GV dot products are reduced across the 32 lanes by one
 // reduce-scatter butterfly (about 2 shuffles per row instead of 5), after
-// which a group of 32/GV adjacent lanes holds row j's dot.
+// which a group of 32/GV adjacent lanes holds row j's dot.  A CSR row whose last
+// step has at most GV entries left ends with a half step (GV/2 gathered rows per
+// half-wave): half the gathers and arithmetic for the same bits (1 M x 27 k
+// user half-sweep: 8.06 -> 7.89 ms).
 #include "als_internal.h"
 
 namespace mirec {
@@ -144,6 +147,23 @@ __device__ __forceinline__ float reduce_scatter(const float (&p)[GV], int c) {
     return d;
 }
 
+// The same for 4 values per lane: lane c of each half ends with the 32-lane sum of value c >> 3.  The additions pair
+// the lanes in the order of reduce_scatter (bit 4, bit 3, the mirror, bits 0 and 1), so an entry's dot product has
+// the same bits whichever of the two reduces it.
+__device__ __forceinline__ float reduce_scatter4(const float (&p)[4], int c) {
+    float q[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) q[i] = swap16_sum(p[i], p[i + 2]);
+    const bool b3 = (c & 8) != 0;
+    const float keep = b3 ? q[1] : q[0];
+    const float send = b3 ? q[0] : q[1];
+    float d = keep + dpp_mov<DPP_ROR8>(send);
+    d += dpp_mov<DPP_HALF_MIRROR>(d);
+    d += dpp_mov<DPP_XOR1>(d);
+    d += dpp_mov<DPP_XOR2>(d);
+    return d;
+}
+
 // Address of this lane's NT columns of gathered row `sel`.  Tables below 4 GiB carry `sel` as a byte offset
 // (one 32-bit add per gather, the base stays in scalar registers); larger ones as a row index.
 template <int NT, bool BIG>
@@ -160,22 +180,24 @@ __device__ __forceinline__ const float* gather_ptr(const float* Y, int sel, int 
 // past the end of the row repeat the row's last entry (always loadable) and get coefficient zero, so no
 // load is conditional.  MODE 0: every entry slot of the step lies inside this wave's on-chip cache,
 // 1: the step straddles the end of the cache (g0 is then a compile-time constant), 2: it lies past it.
-template <int NT, int CAP, bool FIRST, bool BIG, int MODE>
+// GVN = 8: a full step; GVN = 4: the half step that ends a row with at most 8 entries left (entries
+// [g0, g0 + 8), the same assignment to halves and cache slots, half the gathers and arithmetic).
+template <int NT, int CAP, bool FIRST, bool BIG, int MODE, int GVN = GV>
 __device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[NT], const float* __restrict__ Y,
                                             float* cache, int g0, int n, int cur_sel, float cur_dat, int selbase,
                                             int coefbase, int h, int c) {
     constexpr int F = 32 * NT;
     constexpr int G0C = (CAP / STEP) * STEP;
-    float yv[GV][NT];
-    int sel[GV];
+    float yv[GVN][NT];
+    int sel[GVN];
     float* slot = cache + (g0 + h) * F + c * NT;
 #pragma unroll
-    for (int j = 0; j < GV; ++j) {
+    for (int j = 0; j < GVN; ++j) {
         const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
         if (FIRST || !inside) sel[j] = __builtin_amdgcn_ds_bpermute(selbase + 8 * j, cur_sel);
     }
 #pragma unroll
-    for (int j = 0; j < GV; ++j) {
+    for (int j = 0; j < GVN; ++j) {
         const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
         if (FIRST || !inside) {
             load_n<NT>(yv[j], gather_ptr<NT, BIG>(Y, sel[j], c));
@@ -185,14 +207,14 @@ __device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[N
     }
     if constexpr (FIRST) {
 #pragma unroll
-        for (int j = 0; j < GV; ++j) {
+        for (int j = 0; j < GVN; ++j) {
             const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
             if (inside) store_n<NT>(slot + 2 * j * F, yv[j]);
         }
     }
-    float part[GV];
+    float part[GVN];
 #pragma unroll
-    for (int j = 0; j < GV; ++j) {
+    for (int j = 0; j < GVN; ++j) {
         float s0 = yv[j][0] * v[0];
         float s1 = NT > 1 ? yv[j][NT > 1 ? 1 : 0] * v[NT > 1 ? 1 : 0] : 0.f;
 #pragma unroll
@@ -202,14 +224,17 @@ __device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[N
         }
         part[j] = s0 + s1;
     }
-    const float d = reduce_scatter(part, c);
-    const int kkm = g0 + 2 * (c >> 2) + h;
+    float d;
+    if constexpr (GVN == GV) d = reduce_scatter(part, c);
+    else d = reduce_scatter4(part, c);
+    constexpr int LANES = 32 / GVN;  // adjacent lanes of a half that end with the same entry's dot product
+    const int kkm = g0 + 2 * (c / LANES) + h;
     const float w = fabsf(cur_dat) - 1.f;
     float coef = FIRST ? ((cur_dat > 0.f ? cur_dat : 0.f) - w * d) : (w * d);
     coef = kkm < n ? coef : 0.f;
 #pragma unroll
-    for (int j = 0; j < GV; ++j) {
-        const float cj = __int_as_float(__builtin_amdgcn_ds_bpermute(coefbase + 16 * j, __float_as_int(coef)));
+    for (int j = 0; j < GVN; ++j) {
+        const float cj = __int_as_float(__builtin_amdgcn_ds_bpermute(coefbase + 4 * LANES * j, __float_as_int(coef)));
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = fmaf(cj, yv[j][t], acc[t]);
     }
@@ -228,7 +253,8 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
     const int e_idx = lane & 15;
-    const int e_dat = 2 * (c >> 2) + h;
+    const int e_dat = 2 * (c >> 2) + h;   // full step: lanes 4j .. 4j+3 of a half end with entry 2j + h
+    const int e_dat4 = 2 * (c >> 3) + h;  // half step: lanes 8j .. 8j+7
     const int selbase = ((lane & 32) | h) << 2;
     const int coefbase = (lane & 32) << 2;
     const int last = n - 1;
@@ -236,8 +262,9 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
         const int k = g0 + e_idx;
         return indices[k < last ? k : last];
     };
+    // (a step that starts with at most GV entries left is a half step)
     auto load_dat = [&](int g0) __attribute__((always_inline)) {
-        const int k = g0 + e_dat;
+        const int k = g0 + (n - g0 <= GV ? e_dat4 : e_dat);
         return data[k < last ? k : last];
     };
     int nxt_sel = load_sel(0);
@@ -250,7 +277,17 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
             nxt_sel = load_sel(g0 + STEP);
             nxt_dat = load_dat(g0 + STEP);
         }
-        if (g0 + STEP <= CAP) {
+        if (n - g0 <= GV) {
+            if (g0 + GV <= CAP) {
+                sparse_step<NT, CAP, FIRST, BIG, 0, GV / 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+            } else if (CAP % STEP == 0 || g0 >= CAP) {
+                sparse_step<NT, CAP, FIRST, BIG, 2, GV / 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+            } else {
+                if constexpr (CAP % STEP != 0)
+                    sparse_step<NT, CAP, FIRST, BIG, 1, GV / 2>(v, acc, Y, cache, (CAP / STEP) * STEP, n, cur_sel, cur_dat,
+                                                                selbase, coefbase, h, c);
+            }
+        } else if (g0 + STEP <= CAP) {
             sparse_step<NT, CAP, FIRST, BIG, 0>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
         } else if (CAP % STEP == 0 || g0 >= CAP) {
             sparse_step<NT, CAP, FIRST, BIG, 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
