@@ -340,14 +340,15 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
     constexpr int CAP = L::CAP;
     constexpr int SW = L::SW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Gs = smem;
+    // LDS: the waves' staging vectors first (their reads then address with immediates), G, the row caches
+    float* Gs = smem + SW * F;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int h = lane >> 5;
     const int c = lane & 31;
-    float* cache = smem + F * F + w * (CAP * F);
-    float* vec = smem + F * F + SW * (CAP * F) + w * F;
+    float* cache = smem + SW * F + F * F + w * (CAP * F);
+    float* vec = smem + w * F;
 
     for (int i = tid * 4; i < F * F; i += 64 * SW * 4)
         *reinterpret_cast<float4*>(Gs + i) = *reinterpret_cast<const float4*>(G + i);
