@@ -380,6 +380,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 did the single-rank extras above: all ranks tear the group down together
         dist.destroy_process_group()
 
 
