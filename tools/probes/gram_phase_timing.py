@@ -1,6 +1,6 @@
 """Phase timing of the explicit-Gram kernel (library built with -DMIREC_DEBUG_TIMING)."""
 import ctypes, sys, os, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from movie_recommender_system_amd import engine as E, synth, _lib
 dev = torch.device("cuda", 0)
 U, I, F = 1_000_000, 27_000, 128

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from movie_recommender_system_amd import engine as E
 dev = torch.device("cuda", 0)
 for n, f in [(1_000_000, 128), (27_000, 128), (1_000_000, 64)]:
