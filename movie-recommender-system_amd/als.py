@@ -33,6 +33,19 @@ def _check_csr(user_items) -> sp.csr_matrix:
     return user_items
 
 
+_FILTERED = float(np.finfo(np.float32).min)   # -FLT_MAX: the score of a liked / filtered item
+
+
+def _hide_filtered(ids: torch.Tensor, scores: torch.Tensor, mask) -> torch.Tensor:
+    """A user whose filter leaves fewer than N items gets the filtered ones back
+    at the tail of the list with score -FLT_MAX: their ids are replaced by -1
+    so that no caller recommends an item the user already has (the plugin drops
+    negative ids, ``recommender.ALSRecommender._recommend_for_known_user``)."""
+    if mask is None:
+        return ids
+    return torch.where(scores == _FILTERED, torch.full_like(ids, -1), ids)
+
+
 class AlternatingLeastSquares:
     """Implicit-feedback ALS (Hu, Koren, Volinsky) with the conjugate-gradient
     solver of Takacs, Pilaszy and Tikk: ``cg_steps`` (3) warm-started steps per
@@ -139,7 +152,8 @@ class AlternatingLeastSquares:
                   filter_items=None, recalculate_user: bool = False, items=None):
         """Top-N items for one user (scalar ``userid`` -> 1-D arrays) or a batch
         (array -> 2-D arrays); ``user_items`` holds one CSR row per user.  Liked
-        items and ``filter_items`` are scored -FLT_MAX.  Returns (ids int32,
+        items and ``filter_items`` are scored -FLT_MAX and, where fewer than N
+        other items exist, fill the tail with id -1.  Returns (ids int32,
         scores float32), best first; ties by ascending item index."""
         if self.user_factors is None or self.item_factors is None:
             raise ValueError("model has not been fitted")
@@ -173,6 +187,7 @@ class AlternatingLeastSquares:
             Q = E.pad_factors(self.user_factors[uids], Yd.shape[1], dev)
             dmask = None if mask is None else E.DeviceCSR.from_scipy(mask, dev)
             ids, scores = E.topk(Q, Yd, int(N), dmask)
+            ids = _hide_filtered(ids, scores, dmask)
             ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
         if scalar:
             return ids[0], scores[0]
@@ -196,6 +211,7 @@ class AlternatingLeastSquares:
                     m = m.sorted_indices()
                 dmask = E.DeviceCSR.from_scipy(m, dev)
             ids, scores = E.topk(Q, Yd, int(N), dmask)
+            ids = _hide_filtered(ids, scores, dmask)
             return ids.cpu().numpy(), scores.cpu().numpy()
 
     def similar_items(self, itemid, N: int = 10, recalculate_item: bool = False, item_users=None,

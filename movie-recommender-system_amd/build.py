@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(HERE, "libmirec.so")
 SOURCES = ["core.hip", "gram.hip", "als_sweep.hip", "als_short.hip", "topk.hip", "topk_inst_0.hip", "topk_inst_1.hip",
            "topk_inst_2.hip", "topk_inst_3.hip", "topk_inst_4.hip", "topk_inst_5.hip", "lightfm.hip", "lightfm_train.hip", "transpose.hip", "metrics.hip", "build_matrix.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "topk_kernel.h"), os.path.join(CSRC, "topk_planes_kernel.h"), os.path.join(CSRC, "topk_workspace.h"), os.path.join(ROOT, "include", "mirec.h")]
+HEADERS = sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join(ROOT, "include", "mirec.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("MIREC_EXTRA_HIPCC_FLAGS", "").split()
 

@@ -900,11 +900,8 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
     if ((rc = exclusive_scan(chunk_ptr, n1, scratch, stream)) != MIREC_OK) return rc;
     if ((rc = exclusive_scan(multi_ptr, n1, scratch, stream)) != MIREC_OK) return rc;
     if ((rc = exclusive_scan(mslot_ptr, n1, scratch, stream)) != MIREC_OK) return rc;
-    if (nrows > 0) {
-        hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows,
-                           chunk_ptr, multi_ptr, (int32_t*)(plan + L.chunk_row), (int32_t*)(plan + L.multi_row));
-        MIREC_LAUNCH_CHECK();
-    }
+    // The totals come back before anything is written through them: a too small `nnz` argument must end as an
+    // error, not as chunk rows stored past the plan's capacity.
     int32_t totals[4] = {0, 0, 0, 0};
     MIREC_HIP(hipMemcpyAsync(&totals[0], chunk_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
     MIREC_HIP(hipMemcpyAsync(&totals[1], multi_ptr + nrows, 4, hipMemcpyDeviceToHost, stream));
@@ -914,6 +911,11 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
     MIREC_REQUIRE(totals[0] <= L.cap, MIREC_E_INVALID,
                   "mirec_als_plan_build: %d chunks exceed the plan capacity %lld (nnz argument too small?)", totals[0],
                   (long long)L.cap);
+    if (nrows > 0) {
+        hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows,
+                           chunk_ptr, multi_ptr, (int32_t*)(plan + L.chunk_row), (int32_t*)(plan + L.multi_row));
+        MIREC_LAUNCH_CHECK();
+    }
     host_counts[0] = totals[0];
     host_counts[1] = totals[1];
     host_counts[2] = totals[2];

@@ -9,7 +9,8 @@ divide by k instead of len(recs).  Both are computed here from one kernel pass
 over the top-k ids (``mirec_ranking_hits``); the per-user counts are integers and
 the averages are accumulated on the host in user order, so the result equals the
 CPU evaluation bit for bit.  LightFM's ``auc_score`` needs the rank of every
-held-out item among all items and is not covered.
+held-out item among all items: that is ``lightfm.auc_score`` (device ranks
+from ``mirec_lightfm_ranks``).
 """
 
 from __future__ import annotations

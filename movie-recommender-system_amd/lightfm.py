@@ -14,8 +14,8 @@ and offers
 
 Representations are feature-embedding segment-sums (identity features included
 when the matrices carry them, as ``lightfm.data.Dataset`` builds them); the
-score is ``(b_u + b_i) + sum_j u_j i_j`` in that order.  Training (WARP) is out
-of scope; arrays come from a trained model or, in benchmarks, from a generator.
+score is ``(b_u + b_i) + sum_j u_j i_j`` in that order.  ``LightFM`` adds WARP
+training with the adagrad schedule (``fit`` / ``fit_partial``) on the device.
 """
 
 from __future__ import annotations
@@ -247,6 +247,55 @@ class LightFM(LightFMScorer):
         self.user_embedding_gradients = self.user_bias_gradients = None
         self._examples_seen = 0
 
+    # The eight parameter tables live on the device between ``fit_partial`` calls (the reference's training loop
+    # calls it once per epoch, hybrid_docker/utils.py:100-107): an epoch neither uploads nor downloads them.  The
+    # numpy attributes of the same names are read through properties that fetch a table when it is asked for
+    # after the device has moved on; assigning one of them drops the device copies.
+    _PARAMS = ("item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients",
+               "user_embeddings", "user_embedding_gradients", "user_biases", "user_bias_gradients")
+
+    def _sync_params_to_host(self) -> None:
+        st = self.__dict__.get("_dev_par")
+        if st is not None:
+            for name in sorted(st["stale"]):
+                self.__dict__["_h_" + name] = st["t"][name].cpu().numpy()
+            st["stale"].clear()
+
+    def _device_params(self, dev):
+        """The tables as device tensors, uploaded only when the host copies are newer."""
+        st = self.__dict__.get("_dev_par")
+        if st is None or st["device"] != dev:
+            self._sync_params_to_host()
+            st = {"device": dev, "stale": set(),
+                  "t": {n: torch.from_numpy(np.ascontiguousarray(self.__dict__["_h_" + n], dtype=np.float32)).to(dev)
+                        for n in self._PARAMS}}
+            self.__dict__["_dev_par"] = st
+        return st
+
+    def _tables(self, dev):
+        st = self.__dict__.get("_dev_par")
+        if st is not None and st["device"] == dev:   # score from the tables the training updates in place
+            t = st["t"]
+            return {"device": dev, "ue": t["user_embeddings"], "ub": t["user_biases"], "ie": t["item_embeddings"],
+                    "ib": t["item_biases"]}
+        return super()._tables(dev)
+
+    def __getstate__(self):
+        self._sync_params_to_host()
+        state = {k: v for k, v in super().__getstate__().items() if k not in ("_dev_par", "_train_inputs")}
+        for n in self._PARAMS:
+            state[n] = state.pop("_h_" + n, None)
+        return state
+
+    def __setstate__(self, state):
+        state = dict(state)
+        for n in self._PARAMS:
+            if n in state:
+                state["_h_" + n] = state.pop(n)
+        super().__setstate__(state)
+        self.__dict__["_dev_par"] = None
+        self.__dict__["_train_inputs"] = None
+
     def _initialize(self, no_user_features: int, no_item_features: int) -> None:
         # lightfm.LightFM._initialize: items first, then users; adagrad accumulators start at one
         nc = self.no_components
@@ -266,8 +315,23 @@ class LightFM(LightFMScorer):
         self.item_embedding_gradients = None  # start afresh
         return self.fit_partial(interactions, user_features, item_features, sample_weight, epochs, num_threads, verbose)
 
-    def fit_partial(self, interactions, user_features=None, item_features=None, sample_weight=None, epochs: int = 1,
-                    num_threads: int = 1, verbose: bool = False):
+    @staticmethod
+    def _fingerprint(m):
+        """Identity of an input matrix between calls: the object itself plus a cheap digest of its contents (a
+        caller may refill the same object)."""
+        if m is None:
+            return None
+        d = getattr(m, "data", None)
+        return (id(m), type(m).__name__, m.shape, int(m.nnz), None if d is None else float(np.sum(d, dtype=np.float64)),
+                int(np.sum(getattr(m, "indices", getattr(m, "col", np.zeros(0)))[:4096], dtype=np.int64)))
+
+    def _device_inputs(self, dev, interactions, user_features, item_features, sample_weight):
+        """Interactions, feature matrices and sample weights as device arrays; kept from call to call while the
+        caller passes the same objects (the reference's epoch loop does)."""
+        key = (str(dev),) + tuple(self._fingerprint(m) for m in (interactions, user_features, item_features, sample_weight))
+        cached = self.__dict__.get("_train_inputs")
+        if cached is not None and cached["key"] == key:
+            return cached
         coo = sp.coo_matrix(interactions)
         if coo.dtype != np.float32:
             coo = coo.astype(np.float32)
@@ -276,78 +340,159 @@ class LightFM(LightFMScorer):
         itf = sp.csr_matrix(_identity(n_items) if item_features is None else item_features, dtype=np.float32)
         if uf.shape[0] < n_users or itf.shape[0] < n_items:
             raise Exception("Number of feature rows does not cover the interactions")
-        if self.item_embedding_gradients is None:
-            self._initialize(uf.shape[1], itf.shape[1])
-        if uf.shape[1] != self.user_embeddings.shape[0] or itf.shape[1] != self.item_embeddings.shape[0]:
-            raise ValueError("Incorrect number of features in user_features / item_features")
+        sw = None
         if sample_weight is not None:
-            sw = sp.coo_matrix(sample_weight)
-            if sw.shape != coo.shape or not (np.array_equal(sw.row, coo.row) and np.array_equal(sw.col, coo.col)):
+            swm = sp.coo_matrix(sample_weight)
+            if swm.shape != coo.shape or not (np.array_equal(swm.row, coo.row) and np.array_equal(swm.col, coo.col)):
                 raise ValueError("Sample weight and interaction matrix entries must be in the same order")
-            sample_weight = np.ascontiguousarray(sw.data, dtype=np.float32)
-        if num_threads < 1:
-            raise ValueError("Number of threads must be 1 or larger.")
+            sw = np.ascontiguousarray(swm.data, dtype=np.float32)
         pos = sp.csr_matrix(coo)
         pos.sort_indices()
+        up = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(dev)
+        cached = {
+            "key": key, "hold": (interactions, user_features, item_features, sample_weight),  # keeps the ids alive
+            "n_users": n_users, "n_items": n_items, "n_uf": uf.shape[1], "n_if": itf.shape[1], "nnz": int(coo.nnz),
+            "ifp": up(itf.indptr, np.int64), "ifi": up(itf.indices, np.int32), "ifd": up(itf.data, np.float32),
+            "ufp": up(uf.indptr, np.int64), "ufi": up(uf.indices, np.int32), "ufd": up(uf.data, np.float32),
+            "pp": up(pos.indptr, np.int64), "pi": up(pos.indices, np.int32),
+            "uid": up(coo.row, np.int32), "iid": up(coo.col, np.int32), "y": up(coo.data, np.float32),
+            "sw": None if sw is None else up(sw, np.float32),
+        }
+        self.__dict__["_train_inputs"] = cached
+        return cached
+
+    def fit_partial(self, interactions, user_features=None, item_features=None, sample_weight=None, epochs: int = 1,
+                    num_threads: int = 1, verbose: bool = False):
+        if num_threads < 1:
+            raise ValueError("Number of threads must be 1 or larger.")
         dev = E.require_cuda(self.device)
         lib = _lib.require()
         nc = self.no_components
-        up = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(dev)
         with self._lock, torch.cuda.device(dev):
-            d = {
-                "ifp": up(itf.indptr, np.int64), "ifi": up(itf.indices, np.int32), "ifd": up(itf.data, np.float32),
-                "ufp": up(uf.indptr, np.int64), "ufi": up(uf.indices, np.int32), "ufd": up(uf.data, np.float32),
-                "pp": up(pos.indptr, np.int64), "pi": up(pos.indices, np.int32),
-                "uid": up(coo.row, np.int32), "iid": up(coo.col, np.int32), "y": up(coo.data, np.float32),
-                "sw": None if sample_weight is None else up(sample_weight, np.float32),
-            }
-            names = ["item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients",
-                     "user_embeddings", "user_embedding_gradients", "user_biases", "user_bias_gradients"]
-            par = {n: up(getattr(self, n), np.float32) for n in names}
+            d = self._device_inputs(dev, interactions, user_features, item_features, sample_weight)
+            if self.item_embedding_gradients is None:
+                self._initialize(d["n_uf"], d["n_if"])
+            if d["n_uf"] != self.user_embeddings.shape[0] or d["n_if"] != self.item_embeddings.shape[0]:
+                raise ValueError("Incorrect number of features in user_features / item_features")
+            st = self._device_params(dev)
+            par = st["t"]
             ws_bytes = int(lib.mirec_lightfm_warp_workspace_bytes(self.max_sampled))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             for _ in range(int(epochs)):
                 # one permutation and one generator seed per epoch from the model's random state, as the library draws them
-                order = np.arange(coo.nnz, dtype=np.int32)
+                order = np.arange(d["nnz"], dtype=np.int32)
                 self.random_state.shuffle(order)
                 seed = int(self.random_state.randint(0, np.iinfo(np.int32).max))
                 d_order = torch.from_numpy(order).to(dev)
+                st["stale"].update(self._PARAMS)   # from here on the device holds the newer tables
                 _lib.check(lib.mirec_lightfm_warp_epoch(
-                    E._ptr(d["ifp"]), E._ptr(d["ifi"]), E._ptr(d["ifd"]), n_items, itf.shape[1],
-                    E._ptr(d["ufp"]), E._ptr(d["ufi"]), E._ptr(d["ufd"]), uf.shape[1],
+                    E._ptr(d["ifp"]), E._ptr(d["ifi"]), E._ptr(d["ifd"]), d["n_items"], d["n_if"],
+                    E._ptr(d["ufp"]), E._ptr(d["ufi"]), E._ptr(d["ufd"]), d["n_uf"],
                     E._ptr(d["pp"]), E._ptr(d["pi"]), E._ptr(d["uid"]), E._ptr(d["iid"]), E._ptr(d["y"]), E._ptr(d["sw"]),
-                    E._ptr(d_order), coo.nnz,
+                    E._ptr(d_order), d["nnz"],
                     E._ptr(par["item_embeddings"]), E._ptr(par["item_embedding_gradients"]), E._ptr(par["item_biases"]),
                     E._ptr(par["item_bias_gradients"]), E._ptr(par["user_embeddings"]),
                     E._ptr(par["user_embedding_gradients"]), E._ptr(par["user_biases"]), E._ptr(par["user_bias_gradients"]),
                     nc, self.learning_rate, self.item_alpha, self.user_alpha, self.max_sampled, seed,
                     1 if self.serial else 0, self._examples_seen, E._ptr(ws), ws_bytes, E._stream_ptr()),
                     "mirec_lightfm_warp_epoch")
-                self._examples_seen += int(coo.nnz)
-            for n in names:
-                setattr(self, n, par[n].cpu().numpy())
-            self._dev = {}  # the scorer's device tables are stale
-        if not all(np.isfinite(getattr(self, n)).all() for n in ("item_embeddings", "user_embeddings", "item_biases")):
+                self._examples_seen += d["nnz"]
+            self._dev = {}  # device tables uploaded from older host copies are stale
+            finite = all(bool(torch.isfinite(par[n]).all().item()) for n in ("item_embeddings", "user_embeddings", "item_biases"))
+        if not finite:
             raise ValueError("Not all estimated parameters are finite, your model may have diverged. "
                              "Try decreasing the learning rate or normalising feature values and sample weights")
         return self
 
 
-def compute_recommendations(user_id, state, top_k: int = 20, cold_start_tokens=None):
-    """The request path of ``compute_recommendations``
-    (``hybrid_docker/inference.py:129-200``) on the GPU scorer.  ``state`` holds
+def _param_property(name: str) -> property:
+    def getter(self):
+        st = self.__dict__.get("_dev_par")
+        if st is not None and name in st["stale"]:
+            self.__dict__["_h_" + name] = st["t"][name].cpu().numpy()
+            st["stale"].discard(name)
+        return self.__dict__.get("_h_" + name)
+
+    def setter(self, value):
+        if self.__dict__.get("_dev_par") is not None:   # a table written by the caller: the host copies lead again
+            self._sync_params_to_host()
+            self.__dict__["_dev_par"] = None
+        self.__dict__["_h_" + name] = value
+
+    return property(getter, setter)
+
+
+for _name in LightFM._PARAMS:
+    setattr(LightFM, _name, _param_property(_name))
+del _name
+
+
+# The cold-start vocabulary of the reference's request path (hybrid_docker/inference.py:168-177), in its order:
+# one token of each list is drawn for a user the model has never seen.
+COLD_START_GENDERS = ("M", "F")
+COLD_START_JOBS = (
+    "other or not specified", "executive/managerial", "sales/marketing", "college/grad student",
+    "doctor/health care", "academic/educator", "homemaker", "K-12 student", "self-employed", "scientist",
+    "technician/engineer", "clerical/admin", "artist", "tradesman/craftsman", "retired", "unemployed",
+    "programmer", "customer service", "writer", "lawyer", "farmer",
+)
+COLD_START_AGES = ("25-34", "18-24", "35-44", "55-64", "45-54", "65+", "0-17")
+
+
+def draw_cold_start_tokens(rng=None):
+    """The three ``age:/job:/gender:`` tokens of an unknown user, drawn in the
+    reference's order (age, job, gender) with ``rng.choice`` -- ``rng`` is the
+    ``random`` module by default, the generator the reference draws from, or any
+    ``random.Random`` (seeded, a test reproduces the draw)."""
+    import random as _random
+    rng = _random if rng is None else rng
+    return [f"age:{rng.choice(COLD_START_AGES)}", f"job:{rng.choice(COLD_START_JOBS)}",
+            f"gender:{rng.choice(COLD_START_GENDERS)}"]
+
+
+def _user_feature_mapping(state) -> dict:
+    """token -> feature column: ``state["user_feature_mapping"]`` when given,
+    else the private map of the pickled ``lightfm.data.Dataset`` the reference
+    reads (``dataset._user_feature_mapping``, hybrid_docker/inference.py:72)."""
+    fmap = state.get("user_feature_mapping")
+    if fmap is None and state.get("dataset") is not None:
+        fmap = getattr(state["dataset"], "_user_feature_mapping", None)
+    return {} if fmap is None else fmap
+
+
+def build_coldstart_user_row(fmap: dict, tokens, n_features: Optional[int] = None) -> sp.csr_matrix:
+    """1 x n_features CSR row with a one in the column of every known token
+    (hybrid_docker/inference.py:66-83); tokens the vocabulary lacks are skipped,
+    no match at all leaves a zero row (the scores are then the item biases)."""
+    cols = [fmap[t] for t in tokens if t in fmap]
+    n = len(fmap) if n_features is None else int(n_features)
+    return sp.csr_matrix((np.ones(len(cols), dtype=np.float32), ([0] * len(cols), cols)), shape=(1, n))
+
+
+def compute_recommendations(user_id, state, top_k: int = 20, num_threads: int = 4, cold_start_tokens=None, rng=None):
+    """``compute_recommendations`` of the reference's request path
+    (``hybrid_docker/inference.py:129-200``; called as
+    ``compute_recommendations(user_id, state, top_k=top_k)`` at ``:238``) on the
+    GPU scorer: same positional arguments, same result (external item ids, best
+    first).
+
+    ``state`` is what ``load_state`` (``inference.py:89-123``) returns:
     ``model`` (a LightFMScorer), ``user_features``, ``item_features``,
-    ``inv_item_map``, ``user_to_idx`` and, for unknown users,
-    ``user_feature_mapping`` (token -> feature column); ``cold_start_tokens``
-    are the three ``age:/job:/gender:`` tokens the reference draws at random."""
+    ``inv_item_map``, ``user_to_idx`` and, for unknown users, the token ->
+    column map (``user_feature_mapping`` or ``dataset._user_feature_mapping``).
+    A known user is scored from its row of ``user_features``; an unknown one
+    from three tokens drawn at random from the reference's vocabulary
+    (``draw_cold_start_tokens``; ``rng`` seeds the draw, ``cold_start_tokens``
+    replaces it).  ``num_threads`` is accepted and ignored: there are no host
+    threads to size.  Equal scores come out in ascending item order, where
+    numpy's ``argsort()[::-1]`` leaves their order unspecified."""
+    del num_threads
     model: LightFMScorer = state["model"]
     if user_id in state["user_to_idx"]:
         ids, _ = model.recommend([state["user_to_idx"][user_id]], state["user_features"], state["item_features"], top_k)
     else:
-        fmap = state.get("user_feature_mapping", {})
-        cols = [fmap[t] for t in (cold_start_tokens or []) if t in fmap]
-        n_feat = state["user_features"].shape[1]
-        row = sp.csr_matrix((np.ones(len(cols), dtype=np.float32), ([0] * len(cols), cols)), shape=(1, n_feat))
+        tokens = draw_cold_start_tokens(rng) if cold_start_tokens is None else list(cold_start_tokens)
+        row = build_coldstart_user_row(_user_feature_mapping(state), tokens, state["user_features"].shape[1])
         ids, _ = model.recommend(None, row, state["item_features"], top_k)
     return [state["inv_item_map"][int(i)] for i in ids[0] if i >= 0]
 

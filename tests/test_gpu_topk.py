@@ -265,13 +265,85 @@ def test_lightfm_scoring_bit_exact(dev):
     state = {"model": sc, "user_features": p["user_features"], "item_features": p["item_features"],
              "inv_item_map": {i: f"movie{i}" for i in range(n_items)}, "user_to_idx": {"u42": 42},
              "user_feature_mapping": fmap}
-    recs = compute_recommendations("someone-new", state, 20, ["tok1", "tok9", "tok29", "unknown-token"])
+    recs = compute_recommendations("someone-new", state, 20, cold_start_tokens=["tok1", "tok9", "tok29", "unknown-token"])
     row = sp.csr_matrix((np.ones(3, dtype=np.float32), ([0, 0, 0], [n_users + 1, n_users + 9, n_users + 29])),
                         shape=(1, p["user_features"].shape[1]))
     cold = oracle.lightfm_repr(row, p["user_embeddings"], p["user_biases"])
     oid, _ = oracle.lightfm_topk(cold, ir, 20)
     assert recs == [f"movie{i}" for i in oid[0]]
     assert compute_recommendations("u42", state, 20) == [f"movie{i}" for i in ids[0]]
+    assert compute_recommendations("u42", state, top_k=20, num_threads=4) == [f"movie{i}" for i in ids[0]]
+
+
+def test_lightfm_cold_start_as_the_reference_calls_it(dev):
+    """An unknown user through the reference's own call, ``compute_recommendations(user_id, state, top_k=top_k)``
+    (hybrid_docker/inference.py:238), with the state ``load_state`` builds (:116-123: the token map only inside
+    the dataset object): three tokens are drawn from the reference's vocabulary with the ``random`` module, as at
+    :179-183, and the result is the oracle's top-20 for exactly those tokens."""
+    import random
+    from types import SimpleNamespace
+    from movie_recommender_system_amd import LightFMScorer, synth
+    from movie_recommender_system_amd import lightfm as L
+    n_users, n_items = 500, 211
+    p = synth.lightfm_problem(9, n_users, n_items)
+    sc = LightFMScorer(p["user_embeddings"], p["user_biases"], p["item_embeddings"], p["item_biases"])
+    # lightfm.data.Dataset lays the user features out as identity columns first, then the tokens in the order
+    # they were fitted: 7 ages, 21 jobs, 2 genders = the 30 extra columns of the synthetic problem
+    tokens = ([f"age:{a}" for a in L.COLD_START_AGES] + [f"job:{j}" for j in L.COLD_START_JOBS] +
+              [f"gender:{g}" for g in L.COLD_START_GENDERS])
+    assert len(tokens) == p["user_features"].shape[1] - n_users == 30
+    fmap = {f"user{u}": u for u in range(n_users)}
+    fmap.update({t: n_users + j for j, t in enumerate(tokens)})
+    dataset = SimpleNamespace(_user_feature_mapping=fmap, _user_id_mapping={f"user{u}": u for u in range(n_users)},
+                              _item_id_mapping={f"movie{i}": i for i in range(n_items)})
+    state = {"model": sc, "dataset": dataset, "user_features": p["user_features"], "item_features": p["item_features"],
+             "inv_item_map": {v: k for k, v in dataset._item_id_mapping.items()},
+             "user_to_idx": dataset._user_id_mapping}
+    ir = oracle.lightfm_repr(p["item_features"], p["item_embeddings"], p["item_biases"])
+    seen = set()
+    for seed in (1, 2, 3, 4):
+        random.seed(seed)
+        recs = compute_recommendations("a-user-nobody-has-seen", state, top_k=20)
+        drawn = L.draw_cold_start_tokens(random.Random(seed))       # the same three draws, replayed
+        assert [t.split(":")[0] for t in drawn] == ["age", "job", "gender"] and all(t in fmap for t in drawn)
+        cols = [fmap[t] for t in drawn]
+        row = sp.csr_matrix((np.ones(3, dtype=np.float32), ([0, 0, 0], cols)), shape=(1, len(fmap)))
+        oid, _ = oracle.lightfm_topk(oracle.lightfm_repr(row, p["user_embeddings"], p["user_biases"]), ir, 20)
+        assert recs == [f"movie{i}" for i in oid[0]]
+        seen.add(tuple(drawn))
+        # an injected generator gives the same draw without touching the module's state
+        assert compute_recommendations("a-user-nobody-has-seen", state, top_k=20, rng=random.Random(seed)) == recs
+    assert len(seen) > 1, "the draw does not depend on the generator"
+    # a vocabulary without any of the tokens: zero user row, items ranked by their biases (inference.py:75-77)
+    bare = dict(state, dataset=SimpleNamespace(_user_feature_mapping={f"user{u}": u for u in range(n_users)}),
+                user_feature_mapping=None)
+    zero = sp.csr_matrix((1, p["user_features"].shape[1]), dtype=np.float32)
+    oid, _ = oracle.lightfm_topk(oracle.lightfm_repr(zero, p["user_embeddings"], p["user_biases"]), ir, 20)
+    assert compute_recommendations("nobody", bare, top_k=20) == [f"movie{i}" for i in oid[0]]
+
+
+def test_recommend_hides_filtered_items_when_fewer_than_n_remain(dev):
+    """A user who has liked all but three items and asks for ten gets three recommendations: the liked items
+    that pad the device's list (score -FLT_MAX) come back as id -1 and the plugin drops them."""
+    from movie_recommender_system_amd import AlternatingLeastSquares
+    rng = np.random.default_rng(3)
+    U, I, f = 6, 40, 16
+    model = AlternatingLeastSquares(factors=f)
+    model.user_factors = rng.standard_normal((U, f)).astype(np.float32)
+    model.item_factors = rng.standard_normal((I, f)).astype(np.float32)
+    dense = np.zeros((U, I), dtype=np.float32)
+    dense[2, :] = 1.0
+    dense[2, [5, 17, 30]] = 0.0
+    dense[4, ::2] = 1.0
+    M = sp.csr_matrix(dense)
+    ids, sc = model.recommend(2, M[2], N=10)
+    assert sorted(ids[:3].tolist()) == [5, 17, 30] and (ids[3:] == -1).all()
+    assert (sc[3:] == np.finfo(np.float32).min).all() and (sc[:3] > np.finfo(np.float32).min).all()
+    ids, sc = model.recommend(np.array([2, 4]), M[[2, 4]], N=25)
+    assert (ids[0, 3:] == -1).all() and (ids[1, :20] >= 0).all() and (ids[1, 20:] == -1).all()
+    assert not set(ids[1, :20].tolist()) & set(range(0, I, 2))
+    ids_all, _ = model.recommend_all(M, N=10)
+    assert (ids_all[2, 3:] == -1).all() and (ids_all[0] >= 0).all()
 
 
 def test_topk_tie_at_kth_place_within_one_tile(dev):
@@ -289,6 +361,10 @@ def test_topk_tie_at_kth_place_within_one_tile(dev):
         assert ok, f"case {case}: {desc}"
 
 
+MAX_LOW_RANK_OUTLIERS = 12   # of the 400 fixed-seed half-sweep cases
+MAX_SENSITIVE = 40
+
+
 def test_randomised_parity_fixed_seed(dev):
     """A bounded, fixed-seed run of the randomised differential tool: 400 top-K and 400 half-sweep cases
     over random shapes, widths, k, filters, tie patterns and row lengths (deterministic: every case has a
@@ -299,11 +375,17 @@ def test_randomised_parity_fixed_seed(dev):
         "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
+    del fz.DEGENERATE[:], fz.SENSITIVE[:]
     for i in range(400):
         ok, desc = fz.case_topk(np.random.default_rng([11, i]))
         assert ok, f"top-K case {i}: {desc}"
         ok, desc = fz.case_sweep(np.random.default_rng([12, i]))
         assert ok, f"half-sweep case {i}: {desc}"
+    # Half-sweep cases beyond 2e-5 of the oracle are judged row by row (measured rounding sensitivity; for
+    # low-rank systems the error in the A-norm, which is a hard bound too): they must stay the exception.
+    print(f"rounding-sensitive cases {len(fz.SENSITIVE)}, low-rank outlier cases {len(fz.DEGENERATE)} "
+          f"(worst A-norm ratio {max((t[4] for t in fz.DEGENERATE), default=0.0):.2f})")
+    assert len(fz.DEGENERATE) <= MAX_LOW_RANK_OUTLIERS and len(fz.SENSITIVE) <= MAX_SENSITIVE
 
 
 @pytest.mark.timeout(600)

@@ -200,3 +200,28 @@ def test_model_state_is_plain_numpy():
     assert clone.item_norms.tolist() == [1e-10] * 4 or np.allclose(clone.item_norms, 1e-10)
     with pytest.raises(NotImplementedError):
         AlternatingLeastSquares(use_cg=False)
+
+
+def test_lightfm_request_path_signature_and_cold_start_draw():
+    """``compute_recommendations`` keeps the reference's parameters (hybrid_docker/inference.py:129-134) and
+    an unknown user's tokens come from the reference's vocabulary (:168-183), one of each kind, in the
+    reference's order of draws; the row builder follows build_coldstart_user_row (:66-83)."""
+    import inspect
+    import random
+    from movie_recommender_system_amd import lightfm as L
+    params = list(inspect.signature(L.compute_recommendations).parameters.values())
+    assert [p.name for p in params[:4]] == ["user_id", "state", "top_k", "num_threads"]
+    assert params[2].default == 20 and params[3].default == 4
+    assert (len(L.COLD_START_AGES), len(L.COLD_START_JOBS), len(L.COLD_START_GENDERS)) == (7, 21, 2)
+    random.seed(5)
+    drawn = L.draw_cold_start_tokens()
+    r = random.Random(5)
+    assert drawn == [f"age:{r.choice(L.COLD_START_AGES)}", f"job:{r.choice(L.COLD_START_JOBS)}",
+                     f"gender:{r.choice(L.COLD_START_GENDERS)}"]
+    fmap = {"u0": 0, "u1": 1, "age:65+": 2, "job:farmer": 3, "gender:F": 4}
+    row = L.build_coldstart_user_row(fmap, ["age:65+", "job:nothing-like-it", "gender:F"])
+    assert row.shape == (1, 5) and row.indices.tolist() == [2, 4] and row.data.tolist() == [1.0, 1.0]
+    assert L.build_coldstart_user_row(fmap, ["x"]).nnz == 0
+    from types import SimpleNamespace
+    assert L._user_feature_mapping({"dataset": SimpleNamespace(_user_feature_mapping=fmap)}) is fmap
+    assert L._user_feature_mapping({"user_feature_mapping": {"a": 1}, "dataset": None}) == {"a": 1}

@@ -5,7 +5,8 @@ usage: python tools/fuzz_parity.py [--seconds 240] [--seed 1] [--kind topk|sweep
 Draws shapes, widths, k, filters, value scales and tie patterns at random and compares
   top-K (both kernels)      ids and scores, bit for bit
   ALS half-sweep            relative Frobenius distance <= 2e-5 (the tolerance of the parity tests); beyond
-                            it, every row within 20x the distance at which plain fp32 numpy CG lands from float64
+                            it, every row within 20x the distance at which plain fp32 numpy CG lands from float64,
+                            and rows of low-rank systems within 20x the oracle's error in the A-norm
   Gram                      1e-5 of the largest entry, symmetric bit for bit
   LightFM (--kind lightfm)  representations, predict, recommend, predict_rank: bit for bit
   WARP    (--kind warp)     serial epochs: parameters and adagrad accumulators bit for bit
@@ -30,6 +31,7 @@ from movie_recommender_system_amd import engine as E  # noqa: E402
 dev = torch.device("cuda", 0)
 VERBOSE = False
 DEGENERATE = []  # the same, in systems with fewer gathered rows than f / 3, beyond 20x the measured sensitivity
+DEGENERATE_FACTOR = 20.0  # ... which must still end this close (squared A-norm error) to where the oracle ends
 SENSITIVE = []   # sweep cases beyond 2e-5 of the oracle that the float64 statement shows to be rounding-sensitive
 
 
@@ -195,8 +197,29 @@ def case_sweep(rng):
             # reg*I plus a part of rank well below f: four summation orders do not bound the tail of a chaotic
             # iterate (single rows of such systems were seen 25x apart between two numpy orders, and the oracle
             # itself 300x from one of them), and the explicit-Gram kernel's split-bf16 products perturb A at the
-            # 2^-22 level, which such a row amplifies by its condition number; counted and reported, not failed
-            DEGENERATE.append((desc, err, float(rd.max()), float(ro.max())))
+            # 2^-22 level, which such a row amplifies by its condition number.  The iterate is chaotic, how far it
+            # got is not: CG lowers the error in the A-norm from step to step whatever the rounding does to its
+            # directions, so these rows are held to that -- in float64, the device's squared A-norm error
+            # (x - x*)' A (x - x*) must stay within DEGENERATE_FACTOR of the worst of the oracle's and the fp32
+            # numpy runs' (for an indefinite A, which negative weights can produce, the residual |b - A x| takes
+            # its place) -- a lost or wrong entry leaves the error near where the sweep started.
+            worst = 0.0
+            for r, _ in bad:
+                A, b = als_numpy.row_system(m, int(r), Y64, G64)
+                if np.linalg.eigvalsh(A)[0] > 0:
+                    xs = np.linalg.solve(A, b)
+                    measure = lambda x: float((x - xs) @ A @ (x - xs))
+                else:
+                    measure = lambda x: float(np.linalg.norm(b - A @ x) ** 2)
+                ref = max([measure(Xo[r].astype(np.float64))] +
+                          [measure(cg_steps_f32(A, b, X[r], 3, order).astype(np.float64)) for order in (None, 1, 2, 3)])
+                start = measure(X[r].astype(np.float64))
+                worst = max(worst, measure(out[r].astype(np.float64)) / max(ref, 1e-10 * start, 1e-300))
+            DEGENERATE.append((desc, err, float(rd.max()), float(ro.max()), worst))
+            if worst > DEGENERATE_FACTOR:
+                print(f"FAIL {desc}: rel {err:.3e}; a low-rank row ends {worst:.1f}x further from its solution "
+                      f"than the oracle / fp32 numpy", flush=True)
+                ok = False
         else:
             print(f"FAIL {desc}: rel {err:.3e}; {len(bad)} rows beyond their sensitivity", flush=True)
             if VERBOSE:
@@ -405,7 +428,10 @@ def main():
     print(f"rounding-sensitive sweep cases (beyond 2e-5 of the oracle, within their measured sensitivity): {len(SENSITIVE)}"
           + (f"; worst: {worst[0]} rel {worst[1]:.2e} (largest row distance to float64: device {worst[2]:.2e}, oracle {worst[3]:.2e})"
              if worst else ""), flush=True)
-    print(f"outliers in degenerate systems (fewer distinct gathered rows than f / 3): {len(DEGENERATE)}", flush=True)
+    wd = max((t[4] for t in DEGENERATE), default=0.0)
+    print(f"outliers in degenerate systems (fewer distinct gathered rows than f / 3): {len(DEGENERATE)}; largest ratio "
+          f"of the device's squared A-norm error to the oracle's / fp32 numpy's: {wd:.2f} (bound {DEGENERATE_FACTOR:g})",
+          flush=True)
     print(f"done: {n} cases, {fails} failed (seed {args.seed}, kind {args.kind})", flush=True)
     sys.exit(1 if fails else 0)
 
