@@ -8,11 +8,13 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer unless its name starts with `host_`;
- *    the caller owns all memory, the library allocates nothing that outlives a
- *    call and keeps no global state except a thread-local error string;
+ *    the caller owns all memory and the library allocates nothing that outlives
+ *    a call.  Its only state besides the thread-local error string is a per-device
+ *    record of one-off kernel set-up (dynamic-LDS attributes, the device's
+ *    compute-unit count), filled on a device's first launch;
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no entry
- *    point synchronises, except mirec_als_plan_build which returns counts to
- *    the host;
+ *    point synchronises, except mirec_als_plan_build (it returns counts to the
+ *    host) and mirec_lightfm_warp_epoch (it uploads a small table);
  *  - return value 0 = success, negative = error (MIREC_E_*); the message is
  *    available from mirec_last_error() on the calling thread;
  *  - factor matrices are row-major fp32 with row stride `f` floats, where `f`
@@ -84,7 +86,8 @@ int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, 
  *   host_counts out: {number of chunks, number of split rows, number of
  *               partial-result slots, number of rows left to the matrix-free
  *               kernel}
- * mirec_als_plan_build synchronises `stream` before it returns.  The sweep
+ * mirec_als_plan_build synchronises `stream` once (to read the counts) and
+ * leaves the plan's last kernel enqueued on it.  The sweep
  * takes the plan, `chunk_nnz` and `host_counts` exactly as the build left them
  * and a workspace of mirec_als_sweep_workspace_bytes(host_counts, f) bytes.
  * A sweep over an empty row range (row_begin == row_end: a shard that owns no
@@ -138,8 +141,8 @@ int mirec_csr_transpose(const int64_t* indptr, const int32_t* indices, const flo
  * mask_indptr may be null (no filter); it is indexed by query row, and every
  * mask row must list its items in ascending order.
  * ws (device memory, 256-byte aligned, ws_bytes >= mirec_topk_workspace_bytes)
- * is optional scratch: with it, plain scoring (no norms) at f in {64, 96, 128}
- * and k <= 24 runs the selection on bf16 matrix-core scores with an error
+ * is optional scratch: with it, plain scoring (no norms) at any f that is a
+ * multiple of 16 up to 128 and k <= 24 runs the selection on bf16 matrix-core scores with an error
  * margin and re-scores the survivors with the fp32 chain above, so the output
  * is the same bit for bit and arrives about three times sooner.  ws may be
  * null (or the size query 0): the fp32 kernel then does all the work.  The
