@@ -238,29 +238,40 @@ class AlsEngine:
 
     ``user_blocks`` (row ranges, solved in order) / ``item_rows`` restrict the
     rows this engine solves (the shard of one rank); the factor matrices are
-    always held whole.
+    always held whole, the interaction matrix only as far as those rows go.
     """
 
-    def __init__(self, Cui: DeviceCSR, Ciu: Optional[DeviceCSR], X: torch.Tensor, Y: torch.Tensor,
+    def __init__(self, Cui: Optional[DeviceCSR], Ciu: Optional[DeviceCSR], X: torch.Tensor, Y: torch.Tensor,
                  regularization: float, cg_steps: int = 3,
                  user_blocks: Optional[Sequence[Tuple[int, int]]] = None,
-                 item_rows: Optional[Tuple[int, int]] = None, chunk_nnz: int = 0, short_max: Optional[int] = None):
+                 item_rows: Optional[Tuple[int, int]] = None, chunk_nnz: int = 0, short_max: Optional[int] = None,
+                 user_shards: Optional[Sequence[DeviceCSR]] = None, item_shard: Optional[DeviceCSR] = None):
+        """``Cui`` / ``Ciu``: the whole matrix and its transpose (``Ciu`` None: transposed here), sliced to
+        ``user_blocks`` / ``item_rows``.  A rank that holds only its share passes instead ``user_shards`` (one
+        CSR per entry of ``user_blocks``, rows [a, b) of the matrix) and ``item_shard`` (rows ``item_rows`` of
+        the transpose) and leaves ``Cui`` / ``Ciu`` None."""
         self.f = int(X.shape[1])
         assert Y.shape[1] == self.f
         self.X, self.Y = X, Y
         self.reg, self.cg_steps = float(regularization), int(cg_steps)
-        users, items = Cui.shape
-        if Ciu is None:
-            Ciu = Cui.transpose()
+        users, items = int(X.shape[0]), int(Y.shape[0])
         self.user_blocks = [tuple(b) for b in (user_blocks if user_blocks is not None else [(0, users)])]
-        self.item_rows = item_rows or (0, items)
+        self.item_rows = tuple(item_rows) if item_rows is not None else (0, items)
+        if user_shards is None:
+            assert Cui is not None and Cui.shape == (users, items)
+            user_shards = [Cui if (a, b) == (0, users) else Cui.row_slice(a, b) for a, b in self.user_blocks]
+        if item_shard is None:
+            if Ciu is None:
+                Ciu = Cui.transpose()
+            item_shard = Ciu if self.item_rows == (0, items) else Ciu.row_slice(*self.item_rows)
+        assert len(user_shards) == len(self.user_blocks)
         self.plans_u = []
-        for a, b in self.user_blocks:
-            cu = Cui if (a, b) == (0, users) else Cui.row_slice(a, b)
+        for (a, b), cu in zip(self.user_blocks, user_shards):
+            assert cu.shape == (b - a, items), "a user shard must hold exactly the rows of its block"
             self.plans_u.append(SweepPlan(cu, self.f, chunk_nnz, short_max) if b > a else None)
-        ci = Ciu if self.item_rows == (0, items) else Ciu.row_slice(*self.item_rows)
-        self.Ciu_local = ci
-        self.plan_i = SweepPlan(ci, self.f, chunk_nnz, short_max)
+        assert item_shard.shape == (self.item_rows[1] - self.item_rows[0], users)
+        self.Ciu_local = item_shard
+        self.plan_i = SweepPlan(item_shard, self.f, chunk_nnz, short_max)
         lib = _lib.require()
         need = max(lib.mirec_gram_workspace_bytes(users, self.f), lib.mirec_gram_workspace_bytes(items, self.f))
         self.gram_ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=X.device)
@@ -296,6 +307,12 @@ class AlsEngine:
         """The user-side plan of an engine with a single user block."""
         assert len(self.plans_u) == 1
         return self.plans_u[0]
+
+    def resident_matrix_bytes(self) -> int:
+        """Bytes of interaction-matrix storage (row pointers, indices, values; both orientations) this engine
+        keeps on its device."""
+        mats = [p.csr for p in self.plans_u if p is not None] + [self.Ciu_local]
+        return sum(m.indptr.numel() * 8 + m.indices.numel() * 4 + m.data.numel() * 4 for m in mats)
 
     def user_totals(self) -> Tuple[int, int, int, int]:
         """(rows, stored entries, rows of the matrix-free kernel, chunks) over this engine's user blocks."""

@@ -12,43 +12,74 @@
                   Zipf-distributed tokens per item, nc = 15 embeddings.
 
 Degrees and popularity are drawn with numpy (PCG64) on the host; the bulk
-sampling and de-duplication run as torch ops on whatever device is given, so
-the 5e7-entry case takes about a second on the GPU.
+sampling and de-duplication run as torch ops on whatever device is given, in
+chunks of 65 536 users with a random stream each, so the 5e7-entry case takes
+about a second on the GPU and any row range can be generated on its own.
 """
 
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import scipy.sparse as sp
 import torch
 
 
-def interactions_torch(seed: int, n_users: int, n_items: int, mean_degree: float, device="cpu"):
-    """Returns (indptr int64 [U+1], indices int32 [nnz], data fp32 [nnz]) as
-    torch tensors on `device`; rows sorted by column, no duplicates."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+GEN_CHUNK = 1 << 16   # users per generation chunk: each chunk has a random stream of its own
+
+
+def _popularity_cdf(rng, n_items: int) -> np.ndarray:
     rank = rng.permutation(n_items)
     pop = (rank + 10.0) ** -0.9
     pop /= pop.sum()
+    return np.cumsum(pop)
+
+
+def interactions_torch(seed: int, n_users: int, n_items: int, mean_degree: float, device="cpu",
+                       users: Optional[Tuple[int, int]] = None):
+    """Returns (indptr int64 [rows+1], indices int32 [nnz], data fp32 [nnz]) as
+    torch tensors on `device`; rows sorted by column, no duplicates.
+
+    ``users = (u0, u1)`` returns only those rows of the same matrix (``indptr``
+    then starts at 0): popularity and degrees are drawn on the host for all
+    users, the item draws in chunks of ``GEN_CHUNK`` users with one random
+    stream per chunk, so that a rank of a sharded run -- or a caller that walks
+    a large matrix slab by slab -- generates its rows and nothing else, and gets
+    the rows every other split gets."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cdf_h = _popularity_cdf(rng, n_items)
     mu = np.log(mean_degree) - 0.5
     deg = np.clip(np.rint(rng.lognormal(mu, 1.0, size=n_users)), 1, max(1, n_items // 4)).astype(np.int64)
+    u0, u1 = (0, n_users) if users is None else (int(users[0]), int(users[1]))
+    assert 0 <= u0 <= u1 <= n_users
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(int(seed))
-    cdf = torch.from_numpy(np.cumsum(pop)).to(dev)
+    cdf = torch.from_numpy(cdf_h).to(dev)
     cdf[-1] = 1.0
-    deg_t = torch.from_numpy(deg).to(dev)
-    users = torch.repeat_interleave(torch.arange(n_users, device=dev, dtype=torch.int64), deg_t)
-    draws = torch.rand(users.numel(), device=dev, dtype=torch.float64, generator=gen)
-    items = torch.searchsorted(cdf, draws).clamp_(max=n_items - 1)
-    keys = torch.unique(users * n_items + items)  # sorted, duplicates (repeat draws) dropped
-    rows = torch.div(keys, n_items, rounding_mode="floor")
-    cols = (keys - rows * n_items).to(torch.int32)
-    counts = torch.bincount(rows, minlength=n_users)
-    indptr = torch.zeros(n_users + 1, dtype=torch.int64, device=dev)
-    indptr[1:] = torch.cumsum(counts, 0)
+    cols_parts, count_parts = [], []
+    for ch in range(u0 // GEN_CHUNK, -(-u1 // GEN_CHUNK) if u1 > u0 else u0 // GEN_CHUNK):
+        c0, c1 = ch * GEN_CHUNK, min((ch + 1) * GEN_CHUNK, n_users)
+        # chunk 0 keeps the plain seed: matrices of up to GEN_CHUNK users are those of the unchunked generator
+        gen.manual_seed(int(seed) if ch == 0 else (int(seed) * 1_000_003 + ch) % (1 << 62))
+        deg_t = torch.from_numpy(deg[c0:c1]).to(dev)
+        local = torch.repeat_interleave(torch.arange(c1 - c0, device=dev, dtype=torch.int64), deg_t)
+        draws = torch.rand(local.numel(), device=dev, dtype=torch.float64, generator=gen)
+        items = torch.searchsorted(cdf, draws).clamp_(max=n_items - 1)
+        keys = torch.unique(local * n_items + items)  # sorted, duplicates (repeat draws) dropped
+        rows = torch.div(keys, n_items, rounding_mode="floor")
+        cols = (keys - rows * n_items).to(torch.int32)
+        a, b = max(u0, c0) - c0, min(u1, c1) - c0      # the chunk's rows that were asked for
+        if (a, b) != (0, c1 - c0):
+            keep = (rows >= a) & (rows < b)
+            rows, cols = rows[keep], cols[keep]
+        count_parts.append(torch.bincount(rows - a, minlength=b - a))
+        cols_parts.append(cols)
+        del local, draws, items, keys, rows
+    indptr = torch.zeros(u1 - u0 + 1, dtype=torch.int64, device=dev)
+    if count_parts:
+        indptr[1:] = torch.cumsum(torch.cat(count_parts), 0)
+    cols = torch.cat(cols_parts) if cols_parts else torch.zeros(0, dtype=torch.int32, device=dev)
     data = torch.ones(cols.numel(), dtype=torch.float32, device=dev)
     return indptr, cols, data
 

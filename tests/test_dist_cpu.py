@@ -1,7 +1,8 @@
-"""The sharded driver on CPU: 2 gloo ranks with the oracle as the local solver
-give bit-for-bit the factors of the single-process oracle fit (row solves are
-independent given the gathered factors, and every rank recomputes the Gram from
-identical bits)."""
+"""The sharded driver on CPU: gloo ranks that each generate only the rows of their
+own user blocks, exchange them into item-row shards (``shard_item_rows``) and
+solve with the oracle give bit-for-bit the factors of the single-process oracle
+fit (row solves are independent given the gathered factors, and every rank
+recomputes the Gram from identical bits)."""
 
 import os
 import socket
@@ -66,30 +67,54 @@ def _free_port():
     return p
 
 
+def _cpu_transpose(m):
+    """``.T.tocsr()`` through scipy: stands in for the device transpose on CPU tensors."""
+    from movie_recommender_system_amd.engine import DeviceCSR
+    T = sp.csr_matrix(m.to_scipy().T)
+    T.sort_indices()
+    return DeviceCSR.from_scipy(T, torch.device("cpu"))
+
+
 def _worker(rank, world, port, out_dir, nu=300, ni=90, blocks=3, deg=10.0):
     import oracle
+    from movie_recommender_system_amd.engine import DeviceCSR
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        M = synth.interactions(3, nu, ni, deg)
-        Cui = sp.csr_matrix(M * np.float32(40.0))
-        Ciu = sp.csr_matrix(Cui.T)
-        X0, Y0 = oracle.oracle.init_factors(nu, ni, 16, 42)
         users = D.BlockCyclic(nu, world, blocks=blocks)
+        # every rank generates the rows of its own user blocks and nothing else ...
+        shards = []
+        for a, b in users.owned(rank):
+            ip, ix, dt = synth.interactions_torch(3, nu, ni, deg, "cpu", users=(a, b))
+            shards.append((a, b, DeviceCSR(ip, ix, dt * 40.0, (b - a, ni))))
+        # ... and receives the rows of the transposed matrix for its item range
+        ciu_local, ib = D.shard_item_rows(shards, users, ni, rank, transpose=_cpu_transpose)
+        whole = sp.csr_matrix(synth.interactions(3, nu, ni, deg) * np.float32(40.0))
+        want = sp.csr_matrix(whole.T)
+        want.sort_indices()
+        assert ib == D.partition_rows(want.indptr, world)
+        want = want[ib[rank]:ib[rank + 1]]
+        got = ciu_local.to_scipy()
+        assert got.shape == want.shape and np.array_equal(got.indptr, want.indptr)
+        assert np.array_equal(got.indices, want.indices) and np.array_equal(got.data, want.data)
+        held = sum(c.indices.numel() for _, _, c in shards) + ciu_local.indices.numel()
+        X0, Y0 = oracle.oracle.init_factors(nu, ni, 16, 42)
         Xpad = torch.zeros((users.padded, 16), dtype=torch.float32)
         Xpad[:nu] = torch.from_numpy(X0)
         Y = torch.from_numpy(Y0.copy())
         Xn, Yn = Xpad[:nu].numpy(), Y.numpy()   # views: the oracle updates the tensors in place
-        ib = D.partition_rows(Ciu.indptr, world)
+        local_u = {(a, b): c.to_scipy() for a, b, c in shards}
+        local_i = ciu_local.to_scipy()
         drv = D.ShardedAlsDriver(
             Xpad, Y, users, ib,
-            lambda a, b: oracle.als_half_sweep(Cui, Xn, Yn, 0.01, 3, rows=(a, b)),
-            lambda a, b: oracle.als_half_sweep(Ciu, Yn, Xn, 0.01, 3, rows=(a, b)),
+            lambda a, b: oracle.als_half_sweep(local_u[(a, b)], Xn[a:b], Yn, 0.01, 3),
+            lambda a, b: oracle.als_half_sweep(local_i, Yn[a:b], Xn, 0.01, 3),
             rank)
         for _ in range(3):
             drv.iteration()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), X=Xn, Y=Yn, ub=np.array(drv.user_blocks), ib=np.array(ib))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), X=Xn, Y=Yn, ub=np.array(drv.user_blocks), ib=np.array(ib),
+                 held=held, nnz=whole.nnz)
     finally:
         dist.destroy_process_group()
 
@@ -107,6 +132,9 @@ def test_two_ranks_equal_single_process(tmp_path):
     for r in (r0, r1):
         assert np.array_equal(r["X"], Xr)
         assert np.array_equal(r["Y"], Yr)
+    # storage is sharded: the two ranks together hold every entry once per orientation
+    assert int(r0["held"]) + int(r1["held"]) == 2 * int(r0["nnz"])
+    assert 0.35 * 2 * int(r0["nnz"]) < int(r0["held"]) < 0.65 * 2 * int(r0["nnz"])
 
 
 @pytest.mark.timeout(300)

@@ -207,7 +207,7 @@ def test_alpha_applied_once_or_prescaled(dev):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,users,items", [(3, 50, 7), (4, 1000, 3)])
+@pytest.mark.parametrize("world,users,items", [(3, 50, 7), (4, 1000, 3), (2, 60_000, 5_000)])
 def test_sharded_driver_with_shards_without_rows(dev, world, users, items):
     """The sharded device driver on `world` ranks that share this one GPU (gloo, collectives staged through the
     host: tools/rehearse_check.py) where some ranks own no user block or no item at all: factors equal the
@@ -228,21 +228,26 @@ def test_sharded_driver_with_shards_without_rows(dev, world, users, items):
                          timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "factors bit-identical: True" in res.stdout
+    if users >= 10_000:
+        # every rank stores about its share of the interaction matrix, not the whole
+        import re
+        held, whole = map(int, re.search(r"bytes on rank 0: (\d+) of (\d+)", res.stdout).groups())
+        assert held < 0.6 * whole, res.stdout[-500:]
 
 
-@pytest.mark.timeout(600)
-def test_full_size_sweeps_on_sampled_rows_and_loss(dev):
-    """The benchmark's configuration (1 M users x 27 k items, ~48 M interactions, f = 128): after each
-    half-sweep of a device iteration a sample of the solved rows (short and long ones, the longest included)
-    is solved again by the oracle from the same inputs and must agree to the half-sweep tolerance; the run is
-    reproducible bit for bit; the regularised implicit-feedback loss goes down from iteration to iteration."""
+def sampled_parity_run(dev, U, I, mean_degree, seed, f, user_samples, item_samples, with_loss, topk_samples=0,
+                       arbitrate_later_sweeps=False):
+    """Two device iterations over a synthetic matrix; after every half-sweep a sample of the solved rows (random
+    ones, the four longest and two shortest) is solved again by the oracle from the same inputs.  Returns the
+    engine's matrices for further checks."""
     import torch
     from movie_recommender_system_amd import engine as E, synth
-    U, I, f, reg = 1_000_000, 27_000, 128, 0.01
-    indptr, indices, data = synth.interactions_torch(42, U, I, 50.0, dev)
-    Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
+    reg = 0.01
+    indptr, indices, data = synth.interactions_torch(seed, U, I, mean_degree, dev)
+    data *= 40.0
+    Cui = E.DeviceCSR(indptr, indices, data, (U, I))
     Ciu = Cui.transpose()
-    rs = np.random.RandomState(42)
+    rs = np.random.RandomState(seed)
     X0 = torch.from_numpy(rs.rand(U, f).astype(np.float32) * 0.01).to(dev)
     Y0 = torch.from_numpy(rs.rand(I, f).astype(np.float32) * 0.01).to(dev)
     rng = np.random.default_rng(0)
@@ -251,9 +256,8 @@ def test_full_size_sweeps_on_sampled_rows_and_loss(dev):
         ptr = csr.indptr.cpu().numpy()
         ln = np.diff(ptr)
         pick = np.unique(np.r_[rng.integers(0, csr.shape[0], count), np.argsort(ln)[-4:], np.argsort(ln)[:2]])
-        idx = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in pick]) if len(pick) else np.zeros(0, np.int64)
-        t = torch.from_numpy(idx).to(dev)
-        sub = sp.csr_matrix((csr.data[t].cpu().numpy(), csr.indices[t].cpu().numpy(), np.r_[0, np.cumsum(ln[pick])]),
+        idx = torch.cat([torch.arange(int(ptr[r]), int(ptr[r + 1]), device=dev) for r in pick])
+        sub = sp.csr_matrix((csr.data[idx].cpu().numpy(), csr.indices[idx].cpu().numpy(), np.r_[0, np.cumsum(ln[pick])]),
                             shape=(len(pick), csr.shape[1]))
         return pick, sub
 
@@ -263,42 +267,126 @@ def test_full_size_sweeps_on_sampled_rows_and_loss(dev):
         pick, sub = sample_rows(csr, count)
         t = torch.from_numpy(pick).to(dev)
         want = solved_before[t].cpu().numpy().copy()
-        oracle.als_half_sweep(sub, want, other.cpu().numpy(), reg, 3, YtY=G.cpu().numpy())
+        other_h = other.cpu().numpy()
+        oracle.als_half_sweep(sub, want, other_h, reg, 3, YtY=G.cpu().numpy())
         got = solved_after[t].cpu().numpy()
         if rel(got, want) < 2e-5:
             return
         # From the benchmark's start (factors of size 0.01) the first systems are dominated by reg*I and three CG
         # steps leave an iterate that moves with the rounding inside the steps; the float64 statement of the same
         # steps arbitrates: the device may not be further from it than 1.5 x the fp32 oracle is.  Only the first
-        # iteration starts from such factors: every later sweep must meet the tolerance outright.
-        assert it == 0, f"iteration {it} {side} sweep: device-oracle {rel(got, want):.2e} exceeds 2e-5"
+        # iteration starts from such factors: every later sweep must meet the tolerance outright -- unless the
+        # caller says that the rows are so long (millions of entries) that the oracle's own sequential fp32 sums
+        # are what is off, which the same float64 comparison then has to show.
+        assert it == 0 or arbitrate_later_sweeps, \
+            f"iteration {it} {side} sweep: device-oracle {rel(got, want):.2e} exceeds 2e-5"
         arbitrated.append((it, side))
         from oracle import als_numpy
-        ref = als_numpy.half_sweep_f64(sub, solved_before[t].cpu().numpy(), other.cpu().numpy(), reg, 3)
+        ref = als_numpy.half_sweep_f64(sub, solved_before[t].cpu().numpy(), other_h, reg, 3)
         d_dev, d_orc = rel(got, ref), rel(want, ref)
         print(f"sampled rows: device-oracle {rel(got, want):.2e}, device-float64 {d_dev:.2e}, oracle-float64 {d_orc:.2e}")
         assert d_dev < 1.5 * d_orc + 2e-5, (d_dev, d_orc)
 
-    def iteration(X, Y, it):
-        eng = E.AlsEngine(Cui, Ciu, X, Y, reg, 3)
+    X, Y = X0.clone(), Y0.clone()
+    eng = E.AlsEngine(Cui, Ciu, X, Y, reg, 3)
+    host_C = losses = None
+    if with_loss:
+        host_C = sp.csr_matrix((Cui.data.cpu().numpy(), Cui.indices.cpu().numpy(), Cui.indptr.cpu().numpy()), shape=(U, I))
+        losses = [oracle.als_loss(host_C, X.cpu().numpy(), Y.cpu().numpy(), reg)]
+    for it in range(2):
         Xb = X.clone()
         eng.user_sweep()
-        check_side(Cui, Xb, X, Y, eng.G, 1500, it, "user")
+        check_side(Cui, Xb, X, Y, eng.G, user_samples, it, "user")
+        del Xb
         Yb = Y.clone()
         eng.item_sweep()
-        check_side(Ciu, Yb, Y, X, eng.G, 60, it, "item")
-
-    X, Y = X0.clone(), Y0.clone()
-    host_C = sp.csr_matrix((Cui.data.cpu().numpy(), Cui.indices.cpu().numpy(), Cui.indptr.cpu().numpy()), shape=(U, I))
-    losses = [oracle.als_loss(host_C, X.cpu().numpy(), Y.cpu().numpy(), reg)]
-    for it in range(2):
-        iteration(X, Y, it)
-        losses.append(oracle.als_loss(host_C, X.cpu().numpy(), Y.cpu().numpy(), reg))
+        check_side(Ciu, Yb, Y, X, eng.G, item_samples, it, "item")
+        if with_loss:
+            losses.append(oracle.als_loss(host_C, X.cpu().numpy(), Y.cpu().numpy(), reg))
     print(f"sweeps arbitrated by the float64 statement: {arbitrated}")
-    assert set(arbitrated) <= {(0, "user"), (0, "item")}, arbitrated
-    assert losses[2] < losses[1] < losses[0], losses
+    assert arbitrate_later_sweeps or set(arbitrated) <= {(0, "user"), (0, "item")}, arbitrated
+    if with_loss:
+        assert losses[2] < losses[1] < losses[0], losses
+    if topk_samples:
+        # top-20 with the liked-item filter for every user; sampled users recomputed by the oracle, bit for bit
+        ids, sc = E.topk(X, Y, 20, E.DeviceCSR(indptr, indices, data, (U, I)))
+        pick = np.unique(rng.integers(0, U, topk_samples))
+        ptr = indptr.cpu().numpy()
+        idx = torch.cat([torch.arange(int(ptr[u]), int(ptr[u + 1]), device=dev) for u in pick])
+        sub = sp.csr_matrix((np.ones(idx.numel(), np.float32), indices[idx].cpu().numpy(),
+                             np.r_[0, np.cumsum(np.diff(ptr)[pick])]), shape=(len(pick), I))
+        t = torch.from_numpy(pick).to(dev)
+        oid, osc = oracle.topk(X[t].cpu().numpy(), Y.cpu().numpy(), 20, liked=sub)
+        assert np.array_equal(ids[t].cpu().numpy(), oid) and np.array_equal(sc[t].cpu().numpy(), osc)
+    return eng, Cui, Ciu, X0, Y0, X, Y
+
+
+@pytest.mark.timeout(600)
+def test_full_size_sweeps_on_sampled_rows_and_loss(dev):
+    """The benchmark's configuration (1 M users x 27 k items, ~48 M interactions, f = 128): after each
+    half-sweep of a device iteration a sample of the solved rows (short and long ones, the longest included)
+    is solved again by the oracle from the same inputs and must agree to the half-sweep tolerance; the run is
+    reproducible bit for bit; the regularised implicit-feedback loss goes down from iteration to iteration."""
+    import torch
+    from movie_recommender_system_amd import engine as E
+    _, Cui, Ciu, X0, Y0, X, Y = sampled_parity_run(dev, 1_000_000, 27_000, 50.0, 42, 128, 1500, 60, with_loss=True)
     X2, Y2 = X0.clone(), Y0.clone()
-    eng = E.AlsEngine(Cui, Ciu, X2, Y2, reg, 3)
+    eng = E.AlsEngine(Cui, Ciu, X2, Y2, 0.01, 3)
     for _ in range(2):
         eng.iteration()
     assert torch.equal(X2, X) and torch.equal(Y2, Y)
+
+
+@pytest.mark.timeout(900)
+def test_scaled_configuration_sweeps_and_top20_on_sampled_rows(dev):
+    """The scaled configuration on one GPU: 10 M users x 200 k items (seed 43; mean degree 200 gives ~2e9
+    interactions).  The user factors span 5.12 GB, so the item half-sweep gathers through 64-bit addressing,
+    the item factors (102 MB) are past the size up to which every user row goes to the matrix-free kernel, and
+    the longest item rows hold millions of entries.  Same checks as at the benchmark's size -- sampled user and
+    item rows against the oracle after every half-sweep of two iterations -- plus top-20 with the liked-item
+    filter for all users, sampled users bit for bit against the oracle, and a repeated half-sweep giving the
+    same bits."""
+    import torch
+    # Item rows here hold 10 k entries on average and up to millions: the oracle adds them one after the other in
+    # fp32 while the device sums 32-entry tiles on the matrix cores and chunk partials in a fixed tree, so beyond
+    # the first iteration too the distance device-oracle (1e-4) is the oracle's own distance from float64; the
+    # float64 statement arbitrates every sweep that misses 2e-5 (the device must be the closer of the two).
+    eng, Cui, Ciu, X0, Y0, X, Y = sampled_parity_run(dev, 10_000_000, 200_000, SCALED_MEAN_DEGREE, 43, 128, 1500, 60,
+                                                     with_loss=False, topk_samples=1500, arbitrate_later_sweeps=True)
+    assert Cui.nnz > 1_000_000_000 and X.numel() * 4 > (1 << 32)
+    assert eng.plan_i.n_split_rows > 0 and eng.plan_u.n_chunks > 0 and eng.plan_u.n_short_rows > 0
+    before = Y.clone()
+    eng.item_sweep()
+    again = Y.clone()
+    Y.copy_(before)
+    eng.item_sweep()
+    assert torch.equal(Y, again)
+
+
+SCALED_MEAN_DEGREE = 200.0
+
+
+@pytest.mark.parametrize("rows,cols,f,dens", [(3000, 5000, 128, 0.02), (700, 9000, 64, 0.08), (5000, 300, 96, 0.3),
+                                              (64, 20000, 192, 0.2), (2000, 2000, 32, 0.01)])
+def test_wide_addressing_gives_the_same_bits(dev, rows, cols, f, dens):
+    """Gathered tables of 4 GiB and more are addressed by 64-bit row arithmetic instead of 32-bit byte offsets
+    (a template variant of both half-sweep kernels).  Forced here on ordinary tables (``y_rows=0``) over short
+    rows, long rows, split rows and negative confidences: the result equals the narrow variant's bit for bit."""
+    import torch
+    from movie_recommender_system_amd import engine as E
+    rng = np.random.default_rng(rows + cols + f)
+    C = random_csr(rng, rows, cols, dens, negatives=True, empty_rows=(1,), heavy_rows=(0, rows - 1))
+    X = (rng.random((rows, f)) * 0.1).astype(np.float32)
+    Y = (rng.standard_normal((cols, f)) * 0.1).astype(np.float32)
+    dC = E.DeviceCSR.from_scipy(C, dev)
+    dY = torch.from_numpy(Y).to(dev)
+    G = E.gram(dY, 0.01)
+    for chunk, short_max in ((0, None), (256, 64), (0, 1 << 30), (512, 0)):
+        plan = E.SweepPlan(dC, f, chunk, short_max)
+        narrow, wide = torch.from_numpy(X).to(dev), torch.from_numpy(X).to(dev)
+        plan.sweep(narrow, dY, G, 3)
+        plan.sweep(wide, dY, G, 3, y_rows=0)
+        assert torch.equal(narrow, wide), (chunk, short_max)
+    Xo = X.copy()
+    oracle.als_half_sweep(C, Xo, Y, 0.01, 3)
+    assert rel(wide.cpu().numpy(), Xo) < 2e-5

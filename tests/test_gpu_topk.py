@@ -284,6 +284,7 @@ def test_lightfm_cold_start_as_the_reference_calls_it(dev):
     from types import SimpleNamespace
     from movie_recommender_system_amd import LightFMScorer, synth
     from movie_recommender_system_amd import lightfm as L
+    compute_recommendations = L.compute_recommendations
     n_users, n_items = 500, 211
     p = synth.lightfm_problem(9, n_users, n_items)
     sc = LightFMScorer(p["user_embeddings"], p["user_biases"], p["item_embeddings"], p["item_biases"])

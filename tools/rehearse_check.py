@@ -42,25 +42,31 @@ dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 U, I, f = int(os.environ.get("REHEARSE_USERS", 60_000)), int(os.environ.get("REHEARSE_ITEMS", 5_000)), 128
-indptr, indices, data = synth.interactions_torch(7, U, I, 40.0, dev)
-Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
-Ciu = Cui.transpose()
 rs = np.random.RandomState(7)
 X0 = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, f, dev)
 Y0 = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, f, dev)
 
 
 def run(r, w):
-    drv, eng = D.gpu_driver(Cui, Ciu, X0.clone(), Y0.clone(), 0.01, 3, r, w)
+    # every rank generates the rows of its own user blocks only; the item-row shard comes from the exchange
+    shards = []
+    for a, b in D.user_layout(U, w).owned(r):
+        ip, ix, dt = synth.interactions_torch(7, U, I, 40.0, dev, users=(a, b))
+        shards.append((a, b, E.DeviceCSR(ip, ix, dt * 40.0, (b - a, I))))
+    if w == 1:
+        drv, eng = D.gpu_driver(shards[0][2], None, X0.clone(), Y0.clone(), 0.01, 3, 0, 1)
+    else:
+        drv, eng = D.gpu_driver(shards, None, X0.clone(), Y0.clone(), 0.01, 3, r, w)
     for _ in range(2):
         drv.iteration()
     torch.cuda.synchronize()
-    return drv.X.clone(), drv.Y.clone()
+    return drv.X.clone(), drv.Y.clone(), eng.resident_matrix_bytes()
 
 
-Xs, Ys = run(rank, world)
+Xs, Ys, held = run(rank, world)
 if rank == 0:
-    X1, Y1 = run(0, 1)
+    X1, Y1, whole = run(0, 1)
+    print(f"interaction-matrix bytes on rank 0: {held} of {whole} ({held / whole:.2f})")
     ok = torch.equal(Xs, X1) and torch.equal(Ys, Y1)
     print("world", world, "vs 1: factors bit-identical:", ok, "| max abs diff X", float((Xs - X1).abs().max()), "Y",
           float((Ys - Y1).abs().max()))
