@@ -212,6 +212,13 @@ __device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[N
             if (inside) store_n<NT>(slot + 2 * j * F, yv[j]);
         }
     }
+#ifdef MIREC_PROBE_LOADS_ONLY  // timing probe only (wrong results): the gathers and cache traffic without the arithmetic
+#pragma unroll
+    for (int j = 0; j < GVN; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += yv[j][t];
+    return;
+#endif
     float part[GVN];
 #pragma unroll
     for (int j = 0; j < GVN; ++j) {
@@ -252,6 +259,11 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
     constexpr int F = 32 * NT;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+#ifdef MIREC_PROBE_NO_SPARSE  // timing probe only (wrong results): what the kernel costs without the gathered rows
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v[t];
+    return;
+#endif
     const int e_idx = lane & 15;
     const int e_dat = 2 * (c >> 2) + h;   // full step: lanes 4j .. 4j+3 of a half end with entry 2j + h
     const int e_dat4 = 2 * (c >> 3) + h;  // half step: lanes 8j .. 8j+7
@@ -306,6 +318,11 @@ template <int NT>
 __device__ __forceinline__ void symv_short(const float* Gs, float* vec, const float (&v)[NT], float (&out)[NT], int h,
                                            int c) {
     constexpr int F = 32 * NT;
+#ifdef MIREC_PROBE_NO_SYMV  // timing probe only (wrong results): what the kernel costs without the G v products
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t] = v[t];
+    return;
+#endif
     __builtin_amdgcn_wave_barrier();
     if (h == 0) store_n<NT>(vec + c * NT, v);
     __builtin_amdgcn_wave_barrier();
