@@ -60,6 +60,21 @@ size_t mirec_gram_workspace_bytes(int64_t n, int f);
 int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, size_t ws_bytes,
                mirec_stream_t stream);
 
+/* mirec_gram without a workspace argument and without any allocation.  It has
+ * no counterpart in the reference: it exists for callers that cannot allocate
+ * device memory -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  The block partials go to a buffer inside the library
+ * (a static device array of MIREC_GRAM_STATIC_BYTES that every GPU the library
+ * runs on holds until the process ends; its address on a device is looked up
+ * on the first call there).  Same kernels, same result bits as mirec_gram.
+ * Inputs with mirec_gram_workspace_bytes(n, f) above that size are refused
+ * with MIREC_E_WORKSPACE (at f = 128: more than 131072 rows; at f <= 64 every
+ * n fits).  All calls on one GPU share the buffer: calls that overlap there
+ * (different streams or threads) race; calls on one stream are ordered. */
+#define MIREC_GRAM_STATIC_BYTES ((size_t)32 << 20)
+size_t mirec_gram_static_max_bytes(void);
+int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, mirec_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * ALS half-sweep (implicit `_least_squares_cg`, cg_steps = 3 by default):
  * for every row u in [row_begin, row_end) of the CSR matrix, warm-started from

@@ -30,6 +30,8 @@ SIGNATURES = {
     "mirec_factor_width": (_int, [_int, _int]),
     "mirec_gram_workspace_bytes": (_sz, [_i64, _int]),
     "mirec_gram": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _sz, _vp]),
+    "mirec_gram_static_max_bytes": (_sz, []),
+    "mirec_gram_static": (_int, [_vp, _i64, _int, _f32, _vp, _vp]),
     "mirec_als_plan_bytes": (_sz, [_i64, _i64, _i32]),
     "mirec_als_short_cache_rows": (_int, [_int]),
     "mirec_als_plan_build": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _sz, _c.POINTER(_i32), _i32,

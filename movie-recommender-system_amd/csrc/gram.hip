@@ -7,6 +7,8 @@
 // in flight while the current ones are multiplied.  Block partials are then
 // summed in a fixed order (fp64 accumulation, one rounding) and mirrored, so
 // the result is symmetric to the bit and does not depend on scheduling.
+#include <mutex>
+
 #include "common.h"
 
 namespace mirec {
@@ -163,6 +165,48 @@ static int launch_gram(const float* Y, int64_t n, float reg, float* G, float* pa
     return MIREC_OK;
 }
 
+// Block partials of mirec_gram_static: device memory that belongs to the library, one copy per GPU, held from
+// the moment the code object is loaded on a device until the process ends.  Host code never passes this name
+// to a kernel: it is a host-side stand-in; the array's address on a device comes from hipGetSymbolAddress with
+// that device current (static_scratch below).
+constexpr size_t GRAM_STATIC_BYTES = MIREC_GRAM_STATIC_BYTES;
+static __device__ __align__(256) float scratch[GRAM_STATIC_BYTES / sizeof(float)];
+
+static std::mutex scratch_mutex;
+static float* scratch_of[kMaxDevices] = {};
+
+// Device address of `scratch` on the current device (looked up once per device), or nullptr with the error set.
+static float* static_scratch() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) {
+        set_error("mirec_gram_static: cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> guard(scratch_mutex);
+    if (scratch_of[d] == nullptr) {
+        float* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || ptr == nullptr) {
+            set_error("mirec_gram_static: hipGetSymbolAddress failed on device %d: %s", d, hipGetErrorString(e));
+            return nullptr;
+        }
+        scratch_of[d] = ptr;
+    }
+    return scratch_of[d];
+}
+
+static int gram_dispatch(const float* Y, int64_t n, int f, float reg, float* G, float* partials, hipStream_t stream) {
+    switch (f / 32) {
+        case 1: return launch_gram<1>(Y, n, reg, G, partials, stream);
+        case 2: return launch_gram<2>(Y, n, reg, G, partials, stream);
+        case 3: return launch_gram<3>(Y, n, reg, G, partials, stream);
+        case 4: return launch_gram<4>(Y, n, reg, G, partials, stream);
+        case 5: return launch_gram<5>(Y, n, reg, G, partials, stream);
+        case 6: return launch_gram<6>(Y, n, reg, G, partials, stream);
+    }
+    return MIREC_E_UNSUPPORTED;
+}
+
 }  // namespace mirec
 
 extern "C" size_t mirec_gram_workspace_bytes(int64_t n, int f) {
@@ -181,14 +225,24 @@ extern "C" int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G,
                   "mirec_gram: factor width %d is not a multiple of 32 in [32,192]; zero-pad the columns", f);
     MIREC_REQUIRE(ws != nullptr && ws_bytes >= mirec_gram_workspace_bytes(n, f), MIREC_E_WORKSPACE,
                   "mirec_gram: workspace of %zu bytes needed, %zu given", mirec_gram_workspace_bytes(n, f), ws_bytes);
-    float* partials = (float*)ws;
-    switch (f / 32) {
-        case 1: return mirec::launch_gram<1>(Y, n, reg, G, partials, stream);
-        case 2: return mirec::launch_gram<2>(Y, n, reg, G, partials, stream);
-        case 3: return mirec::launch_gram<3>(Y, n, reg, G, partials, stream);
-        case 4: return mirec::launch_gram<4>(Y, n, reg, G, partials, stream);
-        case 5: return mirec::launch_gram<5>(Y, n, reg, G, partials, stream);
-        case 6: return mirec::launch_gram<6>(Y, n, reg, G, partials, stream);
-    }
-    return MIREC_E_UNSUPPORTED;
+    return mirec::gram_dispatch(Y, n, f, reg, G, (float*)ws, stream);
+}
+
+extern "C" size_t mirec_gram_static_max_bytes(void) { return mirec::GRAM_STATIC_BYTES; }
+
+extern "C" int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, mirec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MIREC_REQUIRE(G != nullptr && n >= 0, MIREC_E_INVALID, "mirec_gram_static: null output or negative n");
+    MIREC_REQUIRE(n == 0 || Y != nullptr, MIREC_E_INVALID, "mirec_gram_static: null input");
+    MIREC_REQUIRE(f % 32 == 0 && f >= 32 && f <= 192, MIREC_E_UNSUPPORTED,
+                  "mirec_gram_static: factor width %d is not a multiple of 32 in [32,192]; zero-pad the columns", f);
+    const size_t need = mirec_gram_workspace_bytes(n, f);
+    MIREC_REQUIRE(need <= mirec::GRAM_STATIC_BYTES, MIREC_E_WORKSPACE,
+                  "mirec_gram_static: %lld rows of width %d need %zu bytes of block partials, the library's static "
+                  "buffer holds %zu; use mirec_gram with a caller workspace", (long long)n, f, need,
+                  mirec::GRAM_STATIC_BYTES);
+    float* partials = mirec::static_scratch();
+    if (partials == nullptr) return MIREC_E_HIP;
+    // Nothing has to start at zero: the partial kernel writes every element of the slots the reduction reads.
+    return mirec::gram_dispatch(Y, n, f, reg, G, partials, stream);
 }

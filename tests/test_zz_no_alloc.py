@@ -1,0 +1,65 @@
+"""GPU test of the entry point that allocates nothing: ``mirec_gram_static`` (block partials in a static
+device array inside the library) against ``mirec_gram`` (caller workspace), through the C ABI, bit for bit,
+on two calls in a row -- the second with a smaller input, so stale contents of the shared buffer would show."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def test_gram_static_matches_gram_with_workspace():
+    import torch
+    from movie_recommender_system_amd import _lib
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    lib = _lib.require()
+    cap = int(lib.mirec_gram_static_max_bytes())
+    assert cap == 32 << 20
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(5)
+
+    def both(n, f, reg):
+        Y = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
+        need = int(lib.mirec_gram_workspace_bytes(n, f))
+        assert need <= cap
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        G_ws = torch.full((f, f), float("nan"), dtype=torch.float32, device=dev)
+        G_st = torch.full((f, f), float("nan"), dtype=torch.float32, device=dev)
+        _lib.check(lib.mirec_gram(_ptr(Y), n, f, reg, _ptr(G_ws), _ptr(ws), need, stream), "mirec_gram")
+        before = torch.cuda.memory_allocated(dev)
+        _lib.check(lib.mirec_gram_static(_ptr(Y), n, f, reg, _ptr(G_st), stream), "mirec_gram_static")
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated(dev) == before
+        a, b = G_ws.cpu().numpy(), G_st.cpu().numpy()
+        assert np.isfinite(a).all() and np.array_equal(a, b), f"n={n} f={f}: results differ"
+        ref = Y.cpu().numpy().astype(np.float64)
+        ref = ref.T @ ref + reg * np.eye(f)
+        assert np.abs(b - ref).max() <= 1e-5 * np.abs(ref).max()
+
+    # two calls in a row on the same buffer, the second smaller; then other widths, an empty input and the
+    # largest input the buffer takes at f = 128
+    both(100_000, 128, 0.01)
+    both(3_001, 128, 0.5)
+    both(27_000, 64, 0.01)
+    both(777, 192, 0.01)
+    both(0, 32, 0.25)
+    both(131_072, 128, 0.01)
+    both(17, 128, 0.01)
+    both(1_000_000, 64, 0.01)
+
+    # beyond the buffer: refused with a clear error, nothing launched
+    n_big = 131_073
+    assert int(lib.mirec_gram_workspace_bytes(n_big, 128)) > cap
+    Y = torch.zeros((n_big, 128), dtype=torch.float32, device=dev)
+    G = torch.zeros((128, 128), dtype=torch.float32, device=dev)
+    rc = lib.mirec_gram_static(_ptr(Y), n_big, 128, 0.01, _ptr(G), stream)
+    assert rc == -2 and "static" in _lib.last_error()
+    with pytest.raises(_lib.MirecError):
+        _lib.check(lib.mirec_gram_static(_ptr(Y), 10, 100, 0.01, _ptr(G), stream), "mirec_gram_static")
