@@ -39,11 +39,13 @@ constexpr int MAX_ROW_CHUNKS = 32;   // a row is split into at most this many ch
 //   int32 multi_row[nrows+1]   row of every split row (first n_multi used)
 //   int32 scan scratch
 //   int32 counter              rows left to the matrix-free kernel
+//   int32 short_order[nrows]   those rows, longest first (the first n_short entries count)
+//   sort scratch               used while the plan is built
 //   int32 chunk_row[cap]       row of every chunk
 constexpr int SCAN_TILE = 2048;  // 256 threads x 8 items
 
 struct PlanLayout {
-    size_t chunk_ptr, multi_ptr, mslot_ptr, chunk_row, multi_row, scratch, counter, total;
+    size_t chunk_ptr, multi_ptr, mslot_ptr, chunk_row, multi_row, scratch, counter, short_order, sort_tmp, total;
     int64_t cap;
     int scan_blocks;
 };
@@ -69,6 +71,8 @@ static inline PlanLayout plan_layout(int64_t nrows, int64_t nnz, int32_t chunk_n
     L.multi_row = off; off += arr;
     L.scratch = off;   off += align_up((size_t)L.scan_blocks * 4, 256);
     L.counter = off;   off += 256;
+    L.short_order = off; off += arr;
+    L.sort_tmp = off;  off += align_up(short_order_tmp_bytes(nrows), 256);
     L.chunk_row = off; off += align_up((size_t)L.cap * 4, 256);
     L.total = off;
     return L;
@@ -915,6 +919,10 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
         hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows,
                            chunk_ptr, multi_ptr, (int32_t*)(plan + L.chunk_row), (int32_t*)(plan + L.multi_row));
         MIREC_LAUNCH_CHECK();
+        if (totals[3] > 0 &&
+            (rc = build_short_order(indptr, row_begin, nrows, short_max, (int32_t*)(plan + L.short_order),
+                                    plan + L.sort_tmp, stream)) != MIREC_OK)
+            return rc;
     }
     host_counts[0] = totals[0];
     host_counts[1] = totals[1];
@@ -956,7 +964,7 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     float* partials = (float*)ws;
     if (short_max >= 0 && host_counts[3] > 0) {
         const int rc = launch_als_short(f / 32, y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps,
-                                        stream);
+                                        (const int32_t*)(p + L.short_order), host_counts[3], stream);
         if (rc != MIREC_OK) return rc;
     }
     if (host_counts[0] == 0 && host_counts[1] == 0) return MIREC_OK;
