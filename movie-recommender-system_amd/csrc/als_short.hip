@@ -9,6 +9,12 @@
 // Cache, as the item factors do in the user half-sweep; rows beyond
 // `short_max` go to the explicit-Gram kernel in als_sweep.hip.
 //
+// Two kernels share the passes over the gathered rows and differ in where the
+// dense part, G v, is evaluated: als_short_kernel (every width) on the vector
+// ALU from a copy of G in LDS, als_short_mfma_kernel (F = 64 and 128, the
+// widths of the reference's configurations) on the matrix cores, by wavefronts
+// set aside for it -- see the comment above that kernel.
+//
 // Layout: persistent workgroups of 16 wavefronts (8 beyond F = 128); G (F x F)
 // sits in LDS, shared by all of them; the rest of the LDS is split into one
 // cache per wavefront that keeps the first CAP gathered rows of the current
@@ -434,16 +440,20 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
 //
 // On the vector ALU a product costs F*F/64 fused multiply-adds per lane and a read of all of G from LDS, per
 // row; with the gathers hidden that was a third of the kernel.  A matrix-vector product does not fill a matrix
-// instruction, sixteen of them do: the 16 wavefronts of a workgroup therefore advance in step -- each with a
-// row of its own, through the same passes as above -- and meet for every product: each writes its vector as
-// three bf16 planes (v = hi + mid + lo exactly, as the explicit-Gram kernel splits its rows) into LDS, and
-// wavefront (t, kp) evaluates rows 16t .. 16t+15 of G times all sixteen vectors over its part kp of the k
-// range with v_mfma_f32_16x16x32_bf16 (six plane products per step, the smallest first; fp32 accuracy), from
-// fragments of G that it split once and keeps in registers.  The partial results of the k parts go through
-// LDS and every wavefront adds its own row's in a fixed order.  G is no longer held in LDS, so the row caches
-// grow.  Rows of one batch are of about equal length (the plan lists the rows longest first), which keeps the
-// wavefronts together without anyone waiting long; a wavefront whose row is finished early (or that has no
-// row) still joins the products with whatever vector it holds -- the columns of a product do not mix.
+// instruction, several of them do.  The workgroup therefore has two kinds of wavefronts:
+//   NS = 12 solvers   each with a row of its own, through the same passes as above, but where the vector
+//                     kernel multiplies by G they PUBLISH the vector -- three bf16 planes (v = hi + mid + lo
+//                     exactly, as the explicit-Gram kernel splits its rows) into their row of an LDS image,
+//                     then a sequence number -- run the pass over the gathered rows (the product is not
+//                     needed before its end) and COLLECT the product from LDS;
+//   4 servers         one per SIMD, each holding a quarter of G as split bf16 fragments in registers.  A
+//                     server polls the sequence numbers, and for the vectors that are waiting evaluates its
+//                     bands of G times all of them with v_mfma_f32_16x16x32_bf16 (six plane products per
+//                     k step, the smallest first: fp32 accuracy), stores the columns that were waiting and
+//                     counts them done.
+// Nobody waits at a barrier: a solver waits only for its own product, which the servers evaluate while it is
+// busy with its pass, so solvers keep hiding each other's memory latency as before.  G is no longer held in LDS, so the row caches grow.  A column
+// of a product depends on its vector only, so a row's result does not depend on what else was in flight.
 typedef __attribute__((ext_vector_type(8))) __bf16 sm_bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 sm_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float sm_f32x2;
@@ -471,42 +481,57 @@ __device__ __forceinline__ f32x4 sm_mma(const sm_u32x4& a, const sm_u32x4& b, f3
                                                    0, 0, 0);
 }
 
+// A server starts a sweep when every solver that still has rows has published, or after this many polls with at
+// least one vector waiting (a bound, so that the loop ends whatever the solvers do; with it reached the sweep
+// serves those that wait -- any split of the vectors over sweeps gives the same results).
+#ifndef MIREC_SRV_MAX_POLLS
+#define MIREC_SRV_MAX_POLLS 100000
+#endif
+
 template <int NT>
 struct MfmaShort {
     static_assert(NT == 2 || NT == 4, "matrix-core G v: widths 64 and 128");
     static constexpr int F = 32 * NT;
-    static constexpr int SW = 16;               // wavefronts = vectors of a product
+    static constexpr int NW = 16;               // wavefronts of the workgroup
+    static constexpr int NSRV = 4;              // servers (the last wavefronts: one per SIMD)
+    static constexpr int NS = NW - NSRV;        // solvers
+    static constexpr int COLS = 16;             // columns of a matrix instruction (NS of them used)
     static constexpr int TILES = F / 16;        // 16-row bands of G
     static constexpr int KP = 2;                // parts of the k range
     static constexpr int KSU = (F / 32) / KP;   // 32-wide k steps per part
-    static constexpr int UNITS = TILES * KP;    // (band, part) pairs, one per wavefront (F = 64: eight of the sixteen)
+    static constexpr int UNITS = TILES * KP;    // (band, part) pairs
+    static constexpr int UPS = UNITS / NSRV;    // per server
     static constexpr int CH = F / 8;            // 16-byte chunks of a plane row
     static constexpr int ROWB = 2 * F;          // bytes of a plane row
-    static constexpr int PLANE_FLOATS = SW * ROWB / 4;
+    static constexpr int PLANE_FLOATS = COLS * ROWB / 4;
     static constexpr int PART_ROW = F + 4;      // floats; the odd number of 16-byte chunks spreads the stores over the banks
-    static constexpr int VPL = 0;                                  // three planes of the sixteen vectors
-    static constexpr int PART = VPL + 3 * PLANE_FLOATS;            // [KP][16][PART_ROW]
-    static constexpr int CACHE = PART + KP * SW * PART_ROW;
+    // LDS map (floats): flags; three planes of the vectors; the partial products [KP][COLS][PART_ROW]; row caches
+    static constexpr int FLAGS = 0;             // int pub[16], int done[16], int finished
+    static constexpr int VPL = 64;
+    static constexpr int PART = VPL + 3 * PLANE_FLOATS;
+    static constexpr int CACHE = PART + KP * COLS * PART_ROW;
     static constexpr int TOTAL = 160 * 1024 / 4;
-    static constexpr int CAP_RAW = (TOTAL - CACHE - 64) / (SW * F);
+    static constexpr int CAP_RAW = (TOTAL - CACHE) / (NS * F);
     static constexpr int CAP = CAP_RAW >= 64 ? 64 : (CAP_RAW & ~1);
-    static constexpr int FLOATS = CACHE + SW * CAP * F;
+    static constexpr int FLOATS = CACHE + NS * CAP * F;
     static constexpr size_t BYTES = (size_t)FLOATS * 4;
     // chunk kc of row n sits at position kc ^ swz(n): the sixteen lanes of every ds_read_b128 group then read
     // sixteen different 16-byte bank groups
     __device__ static __forceinline__ int swz(int n) { return (n / (16 / CH)) % CH; }
 };
 
-// G v for the sixteen rows of a batch, in three steps that every thread of the workgroup takes: publish (this
-// wavefront's vector v -> row w of the three bf16 planes in LDS), a workgroup barrier, compute (wavefront
-// (t, kp): rows 16t .. 16t+15 of G times all sixteen vectors over part kp of the k range, from its register
-// fragments Ag of G, result to LDS), a second barrier, collect (the wavefront's own row of the result).  The
-// vector is known before the pass over the gathered rows that needs the product, so the caller puts that pass
-// between compute and the second barrier: the matrix work and the LDS round trips hide behind it.
+__device__ __forceinline__ int lds_load_acquire(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Solver k: vector v -> row k of the three planes, then the sequence number `seq` of this product.
 template <int NT>
-__device__ __forceinline__ void symv_publish(float* smem, const float (&v)[NT], int w, int h, int c) {
+__device__ __forceinline__ void symv_publish(float* smem, const float (&v)[NT], int k, int seq, int lane, int h, int c) {
     using M = MfmaShort<NT>;
-#if defined(MIREC_PROBE_NO_SYMV) || defined(MIREC_PROBE_BARRIERS_ONLY)
+#ifdef MIREC_PROBE_NO_SYMV
     return;
 #endif
     char* vpl = reinterpret_cast<char*>(smem + M::VPL);
@@ -517,101 +542,60 @@ __device__ __forceinline__ void symv_publish(float* smem, const float (&v)[NT], 
             uint32_t hi[2], mid[2], lo[2];
             sm_split3(v[0], v[1], hi[0], mid[0], lo[0]);
             sm_split3(v[2], v[3], hi[1], mid[1], lo[1]);
-            char* dst = vpl + w * M::ROWB + (((c >> 1) ^ M::swz(w)) << 4) + ((c & 1) << 3);
+            char* dst = vpl + k * M::ROWB + (((c >> 1) ^ M::swz(k)) << 4) + ((c & 1) << 3);
             *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
             *reinterpret_cast<uint2*>(dst + PLANEB) = make_uint2(mid[0], mid[1]);
             *reinterpret_cast<uint2*>(dst + 2 * PLANEB) = make_uint2(lo[0], lo[1]);
         } else {
             uint32_t hi, mid, lo;
             sm_split3(v[0], v[1], hi, mid, lo);
-            char* dst = vpl + w * M::ROWB + (((c >> 2) ^ M::swz(w)) << 4) + ((c & 3) << 2);
+            char* dst = vpl + k * M::ROWB + (((c >> 2) ^ M::swz(k)) << 4) + ((c & 3) << 2);
             *reinterpret_cast<uint32_t*>(dst) = hi;
             *reinterpret_cast<uint32_t*>(dst + PLANEB) = mid;
             *reinterpret_cast<uint32_t*>(dst + 2 * PLANEB) = lo;
         }
     }
+    // the release orders the plane stores of the whole wavefront (one instruction stream) before the number
+    int* pub = reinterpret_cast<int*>(smem + M::FLAGS);
+    if (lane == 0) lds_store_release(pub + k, seq);
 }
 
+// Solver k: wait until all servers have counted product `seq` of this solver done, then out = G v.
 template <int NT>
-__device__ __forceinline__ void symv_compute(float* smem, const sm_u32x4 (&Ag)[3][MfmaShort<NT>::KSU], int w, int lane) {
+__device__ __forceinline__ void symv_collect(float* smem, const float (&v)[NT], float (&out)[NT], int k, int seq, int c) {
     using M = MfmaShort<NT>;
-#if defined(MIREC_PROBE_NO_SYMV) || defined(MIREC_PROBE_BARRIERS_ONLY)
-    return;
-#endif
-    const char* vpl = reinterpret_cast<const char*>(smem + M::VPL);
-    float* part = smem + M::PART;
-    constexpr int PLANEB = M::PLANE_FLOATS * 4;
-    if (w < M::UNITS) {
-        const int t = w % M::TILES, kp = w / M::TILES;
-        const int n = lane & 15, q = lane >> 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < M::KSU; ++s) {
-            const int kc = 4 * (kp * M::KSU + s) + q;
-            const char* src = vpl + n * M::ROWB + ((kc ^ M::swz(n)) << 4);
-            const sm_u32x4 b0 = *reinterpret_cast<const sm_u32x4*>(src);
-            const sm_u32x4 b1 = *reinterpret_cast<const sm_u32x4*>(src + PLANEB);
-            const sm_u32x4 b2 = *reinterpret_cast<const sm_u32x4*>(src + 2 * PLANEB);
-            // smallest products first; lo*mid, mid*lo and lo*lo are below 2^-25 of the term and dropped
-            acc = sm_mma(Ag[2][s], b0, acc);
-            acc = sm_mma(Ag[0][s], b2, acc);
-            acc = sm_mma(Ag[1][s], b1, acc);
-            acc = sm_mma(Ag[1][s], b0, acc);
-            acc = sm_mma(Ag[0][s], b1, acc);
-            acc = sm_mma(Ag[0][s], b0, acc);
-        }
-        // lane (n, q) holds rows 16t + 4q .. + 3 of G times vector n
-        *reinterpret_cast<f32x4*>(part + (kp * M::SW + n) * M::PART_ROW + 16 * t + 4 * q) = acc;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void symv_collect(const float* smem, const float (&v)[NT], float (&out)[NT], int w, int c) {
-    using M = MfmaShort<NT>;
-#if defined(MIREC_PROBE_NO_SYMV) || defined(MIREC_PROBE_BARRIERS_ONLY)
+#ifdef MIREC_PROBE_NO_SYMV
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t] = v[t];
     return;
 #endif
-    const float* p0 = smem + M::PART + w * M::PART_ROW + c * NT;
+    const int* done = reinterpret_cast<const int*>(smem + M::FLAGS) + 16;
+    const int want = seq * M::NSRV;
+    while (lds_load_acquire(done + k) != want) __builtin_amdgcn_s_sleep(1);
+    const float* p0 = smem + M::PART + k * M::PART_ROW + c * NT;
     float a0[NT], a1[NT];
     load_n<NT>(a0, p0);
-    load_n<NT>(a1, p0 + M::SW * M::PART_ROW);
+    load_n<NT>(a1, p0 + M::COLS * M::PART_ROW);
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t] = a0[t] + a1[t];
 }
 
-#ifdef MIREC_PROBE_NO_SYMV
-#define SM_BARRIER() do { } while (0)
-#else
-#define SM_BARRIER() __syncthreads()
-#endif
-
-template <int NT, bool BIG>
-__global__ __launch_bounds__(1024) void als_short_mfma_kernel(
-    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
-    int64_t row_begin, const int32_t* __restrict__ order, int64_t n_short, float* X, const float* __restrict__ Y,
-    const float* __restrict__ G, int cg_steps) {
+// Server `srv`: until every solver has finished, evaluate its bands of G times the vectors that wait.
+template <int NT>
+__device__ __forceinline__ void symv_server(float* smem, const float* __restrict__ G, int srv, int lane) {
     using M = MfmaShort<NT>;
     constexpr int F = M::F;
-    constexpr int CAP = M::CAP;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int h = lane >> 5;
-    const int c = lane & 31;
-    float* cache = smem + M::CACHE + w * (CAP * F);
-
-    // fragments of G: rows 16t + m, columns 32 (kp KSU + s) + 8 q .. + 7, split into the three planes
-    sm_u32x4 Ag[3][M::KSU];
-    {
-        const int u = w < M::UNITS ? w : 0;
+    constexpr int PLANEB = M::PLANE_FLOATS * 4;
+    const int n = lane & 15, q = lane >> 4;   // operand lane: column n (a solver's vector), k group q
+    // fragments of G: unit u = (band t, k part kp); rows 16t + (lane & 15), columns 32 (kp KSU + s) + 8 q .. + 7
+    sm_u32x4 Ag[M::UPS][3][M::KSU];
+#pragma unroll
+    for (int j = 0; j < M::UPS; ++j) {
+        const int u = srv * M::UPS + j;
         const int t = u % M::TILES, kp = u / M::TILES;
-        const int m = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int s = 0; s < M::KSU; ++s) {
-            const float* g = G + (16 * t + m) * F + 32 * (kp * M::KSU + s) + 8 * q;
+            const float* g = G + (16 * t + n) * F + 32 * (kp * M::KSU + s) + 8 * q;
             const float4 g0 = *reinterpret_cast<const float4*>(g);
             const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
             uint32_t hi[4], mid[4], lo[4];
@@ -619,35 +603,117 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
             sm_split3(g0.z, g0.w, hi[1], mid[1], lo[1]);
             sm_split3(g1.x, g1.y, hi[2], mid[2], lo[2]);
             sm_split3(g1.z, g1.w, hi[3], mid[3], lo[3]);
-            Ag[0][s] = sm_u32x4{hi[0], hi[1], hi[2], hi[3]};
-            Ag[1][s] = sm_u32x4{mid[0], mid[1], mid[2], mid[3]};
-            Ag[2][s] = sm_u32x4{lo[0], lo[1], lo[2], lo[3]};
+            Ag[j][0][s] = sm_u32x4{hi[0], hi[1], hi[2], hi[3]};
+            Ag[j][1][s] = sm_u32x4{mid[0], mid[1], mid[2], mid[3]};
+            Ag[j][2][s] = sm_u32x4{lo[0], lo[1], lo[2], lo[3]};
         }
     }
+    int* flags = reinterpret_cast<int*>(smem + M::FLAGS);
+    const int* pub = flags;
+    int* done = flags + 16;
+    const int* finished = flags + 32;
+    const char* vpl = reinterpret_cast<const char*>(smem + M::VPL);
+    float* part = smem + M::PART;
+    int seen = 0;    // products of solver n this server has evaluated
+    int polls = 0;
+    for (;;) {
+        // (finished is read first: a solver publishes nothing after it has counted itself finished)
+        const bool all_finished = lds_load_acquire(finished) == M::NS;
+        const int pubv = n < M::NS ? lds_load_acquire(pub + n) : 0;
+        const bool pend = pubv != seen;
+        const unsigned waiting = (unsigned)__builtin_amdgcn_ballot_w64(pend) & 0xffffu;
+        if (waiting == 0u) {
+            if (all_finished) break;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        // The solvers work on rows of equal length (the plan lists them longest first) and so publish at about
+        // the same time: wait until every solver that still has rows has published, and one sweep serves them
+        // all.  Sweeps for one or two vectors each would cost the matrix pipe as much as a full one, and there
+        // would be six times as many (measured on 1 M x 27 k users: 7.5 ms against 6.6 ms for the half-sweep).
+        {
+            const int nfin = lds_load_acquire(finished);
+            if (__builtin_popcount(waiting) < M::NS - nfin && ++polls <= MIREC_SRV_MAX_POLLS) {
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+        }
+        polls = 0;
+#pragma unroll
+        for (int j = 0; j < M::UPS; ++j) {
+            const int u = srv * M::UPS + j;
+            const int t = u % M::TILES, kp = u / M::TILES;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < M::KSU; ++s) {
+                const int kc = 4 * (kp * M::KSU + s) + q;
+                const char* src = vpl + n * M::ROWB + ((kc ^ M::swz(n)) << 4);
+                const sm_u32x4 b0 = *reinterpret_cast<const sm_u32x4*>(src);
+                const sm_u32x4 b1 = *reinterpret_cast<const sm_u32x4*>(src + PLANEB);
+                const sm_u32x4 b2 = *reinterpret_cast<const sm_u32x4*>(src + 2 * PLANEB);
+                // smallest products first; lo*mid, mid*lo and lo*lo are below 2^-25 of the term and dropped
+                acc = sm_mma(Ag[j][2][s], b0, acc);
+                acc = sm_mma(Ag[j][0][s], b2, acc);
+                acc = sm_mma(Ag[j][1][s], b1, acc);
+                acc = sm_mma(Ag[j][1][s], b0, acc);
+                acc = sm_mma(Ag[j][0][s], b1, acc);
+                acc = sm_mma(Ag[j][0][s], b0, acc);
+            }
+            // lane (n, q) holds rows 16t + 4q .. + 3 of G times vector n; only columns that were waiting count
+            // (the others were read while their solver may have been writing them)
+            if (pend) *reinterpret_cast<f32x4*>(part + (kp * M::COLS + n) * M::PART_ROW + 16 * t + 4 * q) = acc;
+        }
+        seen = pubv;
+        // the release orders this wavefront's stores before the counts
+        if (pend && q == 0) __hip_atomic_fetch_add(done + n, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
 
-    const int64_t nbatch = (n_short + M::SW - 1) / M::SW;
-    for (int64_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
-        const int64_t i = b * M::SW + w;
-        const bool active = i < n_short;  // wave-uniform
-        const int64_t row = row_begin + (active ? order[i] : 0);
+template <int NT, bool BIG>
+__global__ __launch_bounds__(1024) void als_short_mfma_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
+    int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G, int cg_steps,
+    const int32_t* __restrict__ order, int64_t n_short) {
+    using M = MfmaShort<NT>;
+    constexpr int F = M::F;
+    constexpr int CAP = M::CAP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int* flags = reinterpret_cast<int*>(smem + M::FLAGS);
+    if (tid < 64) flags[tid] = 0;
+    __syncthreads();
+    if (w >= M::NS) {
+        symv_server<NT>(smem, G, w - M::NS, lane);
+        return;
+    }
+    const int h = lane >> 5;
+    const int c = lane & 31;
+    float* cache = smem + M::CACHE + w * (CAP * F);
+    int seq = 0;  // products this solver has published
+
+    // the solvers of a workgroup take twelve consecutive rows of the plan's list (rows of about equal length)
+    const int64_t stride = (int64_t)gridDim.x * M::NS;
+    for (int64_t r = (int64_t)blockIdx.x * M::NS + w; r < n_short; r += stride) {
+        const int64_t row = row_begin + order[r];
         const int64_t rs = indptr[row];
-        const int n = active ? (int)(indptr[row + 1] - rs) : 0;
+        const int n = (int)(indptr[row + 1] - rs);
         float* xg = X + row * F + c * NT;
         float x[NT], rr[NT], p[NT], Ap[NT], acc[NT];
+        if (n == 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) x[t] = 0.f;
-        bool alive = n > 0;
-        if (alive) load_n<NT>(x, xg);
+            for (int t = 0; t < NT; ++t) x[t] = 0.f;
+            if (h == 0) store_n<NT>(xg, x);
+            continue;
+        }
+        load_n<NT>(x, xg);
         const int32_t* ind = indices + rs;
         const float* dat = data + rs;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = 0.f;
-        symv_publish<NT>(smem, x, w, h, c);
-        SM_BARRIER();  // the sixteen vectors are in LDS
-        symv_compute<NT>(smem, Ag, w, lane);
-        if (alive) sparse_pass<NT, CAP, true, BIG>(x, acc, ind, dat, Y, cache, n, lane, h, c);
-        SM_BARRIER();  // the products are in LDS; the planes may be overwritten
-        symv_collect<NT>(smem, x, Ap, w, c);
+
+        symv_publish<NT>(smem, x, w, ++seq, lane, h, c);
+        sparse_pass<NT, CAP, true, BIG>(x, acc, ind, dat, Y, cache, n, lane, h, c);
+        symv_collect<NT>(smem, x, Ap, w, seq, c);
         float part = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -656,49 +722,42 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
             part = fmaf(rr[t], rr[t], part);
         }
         float rsold = half_sum(part);
-        alive = alive && !(rsold < 1e-20f);
+        if (rsold < 1e-20f) continue;
         for (int it = 0; it < cg_steps; ++it) {
-            symv_publish<NT>(smem, p, w, h, c);
-            SM_BARRIER();
-            symv_compute<NT>(smem, Ag, w, lane);
-            if (alive) sparse_pass<NT, CAP, false, BIG>(p, acc, ind, dat, Y, cache, n, lane, h, c);
-            SM_BARRIER();
-            symv_collect<NT>(smem, p, Ap, w, c);
-            if (alive) {
-                part = 0.f;
+            symv_publish<NT>(smem, p, w, ++seq, lane, h, c);
+            sparse_pass<NT, CAP, false, BIG>(p, acc, ind, dat, Y, cache, n, lane, h, c);
+            symv_collect<NT>(smem, p, Ap, w, seq, c);
+            part = 0.f;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    Ap[t] += acc[t];
-                    part = fmaf(p[t], Ap[t], part);
-                }
-                const float alpha = rsold / half_sum(part);
-                part = 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    x[t] = fmaf(alpha, p[t], x[t]);
-                    rr[t] = fmaf(-alpha, Ap[t], rr[t]);
-                    part = fmaf(rr[t], rr[t], part);
-                }
-                const float rsnew = half_sum(part);
-                if (rsnew < 1e-20f) {
-                    alive = false;
-                } else {
-                    const float beta = rsnew / rsold;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) p[t] = fmaf(beta, p[t], rr[t]);
-                    rsold = rsnew;
-                }
+            for (int t = 0; t < NT; ++t) {
+                Ap[t] += acc[t];
+                part = fmaf(p[t], Ap[t], part);
             }
+            const float alpha = rsold / half_sum(part);
+            part = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                x[t] = fmaf(alpha, p[t], x[t]);
+                rr[t] = fmaf(-alpha, Ap[t], rr[t]);
+                part = fmaf(rr[t], rr[t], part);
+            }
+            const float rsnew = half_sum(part);
+            if (rsnew < 1e-20f) break;
+            const float beta = rsnew / rsold;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) p[t] = fmaf(beta, p[t], rr[t]);
+            rsold = rsnew;
         }
-        // rows without entries are set to zero; a row whose start residual vanished keeps its (unchanged) x
-        if (active && h == 0) store_n<NT>(xg, x);
+        if (h == 0) store_n<NT>(xg, x);
     }
+    // every product this solver published has been collected: the servers may stop once all solvers are here
+    if (lane == 0) __hip_atomic_fetch_add(flags + 32, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <int NT, bool BIG>
 static int launch_short_mfma(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
-                             const int32_t* order, int64_t n_short, float* X, const float* Y, const float* G,
-                             int cg_steps, hipStream_t stream) {
+                             float* X, const float* Y, const float* G, int cg_steps, const int32_t* order,
+                             int64_t n_short, hipStream_t stream) {
     using M = MfmaShort<NT>;
     static_assert(M::CAP >= 2, "no room for a row cache");
     static OncePerDevice once;  // idempotent; a race only repeats the call
@@ -714,11 +773,11 @@ static int launch_short_mfma(const int64_t* indptr, const int32_t* indices, cons
         MIREC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         *attr_done = true;
     }
-    int64_t blocks = (n_short + M::SW - 1) / M::SW;
+    int64_t blocks = (n_short + M::NS - 1) / M::NS;
     if (blocks > cus) blocks = cus;
     if (blocks < 1) return MIREC_OK;
-    hipLaunchKernelGGL((als_short_mfma_kernel<NT, BIG>), dim3((unsigned)blocks), dim3(64 * M::SW), M::BYTES, stream,
-                       indptr, indices, data, row_begin, order, n_short, X, Y, G, cg_steps);
+    hipLaunchKernelGGL((als_short_mfma_kernel<NT, BIG>), dim3((unsigned)blocks), dim3(64 * M::NW), M::BYTES, stream,
+                       indptr, indices, data, row_begin, X, Y, G, cg_steps, order, n_short);
     MIREC_LAUNCH_CHECK();
     return MIREC_OK;
 }
@@ -761,8 +820,8 @@ static int launch_short_nt(int64_t y_rows, const int64_t* indptr, const int32_t*
 #ifndef MIREC_SHORT_VALU_ONLY
     if constexpr (NT == 2 || NT == 4) {
         if (order != nullptr)
-            return big ? launch_short_mfma<NT, true>(indptr, indices, data, row_begin, order, n_short, X, Y, G, cg_steps, stream)
-                       : launch_short_mfma<NT, false>(indptr, indices, data, row_begin, order, n_short, X, Y, G, cg_steps, stream);
+            return big ? launch_short_mfma<NT, true>(indptr, indices, data, row_begin, X, Y, G, cg_steps, order, n_short, stream)
+                       : launch_short_mfma<NT, false>(indptr, indices, data, row_begin, X, Y, G, cg_steps, order, n_short, stream);
     }
 #endif
     return big ? launch_short<NT, true>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream)
@@ -787,13 +846,14 @@ int launch_als_short(int nt, int64_t y_rows, const int64_t* indptr, const int32_
 int als_short_cache_rows(int nt) {
     switch (nt) {
         case 1: return ShortLds<1>::CAP;
-#ifndef MIREC_SHORT_VALU_ONLY
+#ifdef MIREC_SHORT_VALU_ONLY
+        case 2: return ShortLds<2>::CAP;
+        case 4: return ShortLds<4>::CAP;
+#else
         case 2: return MfmaShort<2>::CAP;
         case 4: return MfmaShort<4>::CAP;
 #endif
-        case 2 + 100: return ShortLds<2>::CAP;
         case 3: return ShortLds<3>::CAP;
-        case 4 + 100: return ShortLds<4>::CAP;
         case 5: return ShortLds<5>::CAP;
         case 6: return ShortLds<6>::CAP;
     }
