@@ -571,7 +571,9 @@ __device__ __forceinline__ void symv_collect(float* smem, const float (&v)[NT], 
 #endif
     const int* done = reinterpret_cast<const int*>(smem + M::FLAGS) + 16;
     const int want = seq * M::NSRV;
+#ifndef MIREC_PROBE_NO_WAIT  // timing probe only (wrong results): the solver does not wait for its product
     while (lds_load_acquire(done + k) != want) __builtin_amdgcn_s_sleep(1);
+#endif
     const float* p0 = smem + M::PART + k * M::PART_ROW + c * NT;
     float a0[NT], a1[NT];
     load_n<NT>(a0, p0);
@@ -639,6 +641,7 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
             }
         }
         polls = 0;
+#ifndef MIREC_PROBE_NO_MFMA  // timing probe only (wrong results): the servers count products done without evaluating them
 #pragma unroll
         for (int j = 0; j < M::UPS; ++j) {
             const int u = srv * M::UPS + j;
@@ -663,6 +666,7 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
             // (the others were read while their solver may have been writing them)
             if (pend) *reinterpret_cast<f32x4*>(part + (kp * M::COLS + n) * M::PART_ROW + 16 * t + 4 * q) = acc;
         }
+#endif
         seen = pubv;
         // the release orders this wavefront's stores before the counts
         if (pend && q == 0) __hip_atomic_fetch_add(done + n, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
