@@ -102,9 +102,19 @@ int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, mir
  *               partial-result slots, number of rows left to the matrix-free
  *               kernel}
  * mirec_als_plan_build synchronises `stream` once (to read the counts) and
- * leaves the plan's last kernel enqueued on it.  The sweep
- * takes the plan, `chunk_nnz` and `host_counts` exactly as the build left them
- * and a workspace of mirec_als_sweep_workspace_bytes(host_counts, f) bytes.
+ * leaves the plan's last kernel enqueued on it.  The sweep takes the plan,
+ * `chunk_nnz` and `host_counts` exactly as the build left them and a workspace
+ * of mirec_als_sweep_workspace_bytes(host_counts, f) bytes (needed whenever the
+ * plan has chunks).
+ *   G           must be the Gram of Y plus reg * I (mirec_gram): besides entering
+ *               every A_u, its diagonal bounds the entries of Y, from which the
+ *               explicit-Gram kernel takes the power of two that scales its fp16
+ *               matrix-core operands (an entry of Y beyond sqrt(max G_jj) may
+ *               overflow them)
+ *   conf_max    the largest |c| over the stored entries -- of the whole matrix,
+ *               so that every shard of a multi-GPU fit scales alike; an upper
+ *               bound does; 0 = not known: the sweep then finds it with one pass
+ *               over the values of its rows
  * A sweep over an empty row range (row_begin == row_end: a shard that owns no
  * rows) returns MIREC_OK without reading any other argument. */
 int mirec_als_short_cache_rows(int f);
@@ -116,7 +126,8 @@ size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], int f);
 int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                          int64_t row_end, int64_t nnz, float* X, const float* Y, int64_t y_rows, const float* G, int f,
                          int cg_steps, const void* plan, int32_t chunk_nnz, int32_t short_max,
-                         const int64_t host_counts[4], void* ws, size_t ws_bytes, mirec_stream_t stream);
+                         const int64_t host_counts[4], float conf_max, void* ws, size_t ws_bytes,
+                         mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Interaction-matrix build (`build_matrix`, als/als.py:107-123, after the ids

@@ -38,7 +38,7 @@ SIGNATURES = {
                                     _c.POINTER(_i64), _vp]),
     "mirec_als_sweep_workspace_bytes": (_sz, [_c.POINTER(_i64), _int]),
     "mirec_als_half_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _int, _int, _vp, _i32, _i32,
-                                    _c.POINTER(_i64), _vp, _sz, _vp]),
+                                    _c.POINTER(_i64), _f32, _vp, _sz, _vp]),
     "mirec_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mirec_csr_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mirec_lightfm_warp_workspace_bytes": (_sz, [_int]),

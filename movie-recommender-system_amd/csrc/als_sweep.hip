@@ -10,13 +10,18 @@
 //     A += sum_k (|c_k|-1) y_k y_k^T      (only the 16x16 tiles on or above the
 //                                          diagonal)
 //     b += sum_k max(c_k,0) y_k           (fp32 vector ALU)
-// The Gram runs on v_mfma_f32_16x16x32_bf16 at fp32 accuracy: each scaled row
-// z_k = sqrt(||c_k|-1|) y_k is split exactly into three bf16 planes
-// z = hi + mid + lo (8 + 8 + 8 significant bits) and a tile accumulates the six
-// plane products down to hi*lo; the dropped ones are below 2^-26 of the term
-// (measured 2.7e-8 of sum|products| against 1.1e-7 for an fp32 fma chain), at
-// 6/16 of the matrix-core time of the fp32 instruction.  An entry with
-// |c_k| < 1 has a negative weight: its sign is applied to the left operand.
+// The Gram runs on v_mfma_f32_16x16x32_f16 at fp32 accuracy: each scaled row
+// z_k = 2^s sqrt(||c_k|-1|) y_k is split into two fp16 planes z = hi + mid
+// (11 + 11 significant bits; the remainder z - hi is exact in fp32) and a tile
+// accumulates the three plane products mid*hi, hi*mid, hi*hi; the dropped
+// mid*mid is below 2^-22 of the term, the rounding of mid likewise -- measured,
+// an entry of A lands as close to its float64 value as with an fp32 fma chain
+// or closer -- at 3/16 of the matrix-core time of the fp32 instruction.  The
+// power of two 2^s (one per launch, from the largest diagonal entry of G and
+// the largest confidence) puts the largest |z| just below 2^15, so that no hi
+// overflows fp16 and every mid that matters is a normal number; the sums are
+// scaled back by 2^-2s, exactly, when they leave the accumulators.  An entry
+// with |c_k| < 1 has a negative weight: its sign is applied to the left operand.
 // Rows that fit one chunk are finished in the same workgroup: A + G is written
 // to LDS (aliasing the gather tiles) and wave 0 runs the CG steps on it.  Rows
 // split over several chunks store their partial (A, b) to a workspace slot; a
@@ -291,13 +296,17 @@ __device__ unsigned long long mirec_dbg[16];
 //   diagonal are accumulated (NB = F/16 bands).  Wave w of the NT waves owns
 //   band-rows w and NB-1-w: (NB-w) + (w+1) = NB+1 tiles each, so the matrix
 //   pipes of the four SIMDs are evenly loaded.
-//   A tile of 32 gathered rows sits in LDS as three bf16 planes [column][32
-//   entries] (64-byte rows of four 16-byte chunks, chunk q of column c stored
-//   at position q ^ ((c >> 1) & 3)): lane (m, q) of an MFMA operand reads the
-//   eight entries 8q..8q+7 of column 16*band + m with one conflict-free
-//   ds_read_b128, and the same image serves as left and right operand.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+//   A tile of 32 gathered rows sits in LDS as two fp16 planes [column][32
+//   entries]: 64-byte rows of four 16-byte chunks; column c has row
+//   c ^ ((c >> 2) & 1) and its chunk q sits at position q ^ swz(c).  Lane (m, q)
+//   of an MFMA operand reads the eight entries 8q..8q+7 of column 16*band + m
+//   with one ds_read_b128, a producer thread stores the eight entries of one
+//   column with one ds_write_b128; with this placement neither has a bank
+//   conflict (the 16 lanes of a read group cover 16 different 16-byte bank
+//   groups, the 8 lanes of a store group 8), and the same image serves as left
+//   and right operand.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // one MFMA operand (8 bf16) = one LDS chunk
 
@@ -307,13 +316,17 @@ struct GramCfg {
     static constexpr int NB = 2 * NT;
     static constexpr int NTHR = 64 * NT;
     static constexpr int NTILES = NB * (NB + 1) / 2;
+    static constexpr int NPLANES = 2;
     static constexpr int PLANE_BYTES = F * 64;
-    static constexpr int TILE_BYTES = 3 * PLANE_BYTES;
+    static constexpr int TILE_BYTES = NPLANES * PLANE_BYTES;
     static constexpr int TILE_FLOATS = TILE_BYTES / 4;
     static constexpr int BIGN = (F * F > 2 * TILE_FLOATS) ? F * F : 2 * TILE_FLOATS;
     static constexpr int PART_STRIDE = NTILES * 256 + F;  // floats of one partial-result slot
     // LDS map (floats): [0, BIGN) gather tiles / A; sign masks of the two tiles; b partials of the four entry
     // groups; b; the CG work vector; the CG partial products
+    // row of column c in a plane, and the swizzle of its chunks (both depend on c & 15 only)
+    __host__ __device__ static constexpr int col_row(int c) { return c ^ ((c >> 2) & 1); }
+    __host__ __device__ static constexpr int col_swz(int c) { return ((c >> 1) & 1) | (((c >> 3) & 1) << 1); }
     static constexpr int SMASK = BIGN;
     static constexpr int BRED = SMASK + 2 * 16;
     static constexpr int BVEC = BRED + 4 * F;
@@ -336,44 +349,56 @@ struct WaveAcc {
     f32x4 a1[N1];
 };
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+__device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
     const f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 
-// Two entries (a, b) x two columns (x, y) -> for each column three words of packed bf16 pairs (entry a in the
-// low half) with hi + mid + lo == value exactly to 24 bits: round to nearest at every level, each remainder
-// exact in fp32.  The remainders are formed per entry on column pairs (packed fp32 ops on adjacent registers).
-__device__ __forceinline__ void split3x2(f32x2 a, f32x2 b, uint32_t (&hi)[2], uint32_t (&mid)[2], uint32_t (&lo)[2]) {
-    hi[0] = cvt_pk_bf16(a[0], b[0]);
-    hi[1] = cvt_pk_bf16(a[1], b[1]);
-    a -= f32x2{__uint_as_float(hi[0] << 16), __uint_as_float(hi[1] << 16)};
-    b -= f32x2{__uint_as_float(hi[0] & 0xffff0000u), __uint_as_float(hi[1] & 0xffff0000u)};
-    mid[0] = cvt_pk_bf16(a[0], b[0]);
-    mid[1] = cvt_pk_bf16(a[1], b[1]);
-    a -= f32x2{__uint_as_float(mid[0] << 16), __uint_as_float(mid[1] << 16)};
-    b -= f32x2{__uint_as_float(mid[0] & 0xffff0000u), __uint_as_float(mid[1] & 0xffff0000u)};
-    lo[0] = cvt_pk_bf16(a[0], b[0]);
-    lo[1] = cvt_pk_bf16(a[1], b[1]);
+// Two entries (a, b) x two columns (x, y) -> for each column two words of packed fp16 pairs (entry a in the
+// low half) with hi + mid == value to 22 bits: round to nearest at both levels, the remainder exact in fp32.
+// The remainders are formed per entry on column pairs (packed fp32 ops on adjacent registers).
+__device__ __forceinline__ void split2x2(f32x2 a, f32x2 b, uint32_t (&hi)[2], uint32_t (&mid)[2]) {
+    hi[0] = cvt_pk_f16(a[0], b[0]);
+    hi[1] = cvt_pk_f16(a[1], b[1]);
+#ifdef MIREC_PROBE_NO_SPLIT  // timing probe only (wrong results): what the producers cost without the plane split
+    mid[0] = hi[0]; mid[1] = hi[1];
+    return;
+#endif
+    const f16x2 h0 = __builtin_bit_cast(f16x2, hi[0]), h1 = __builtin_bit_cast(f16x2, hi[1]);
+    a -= f32x2{(float)h0[0], (float)h1[0]};
+    b -= f32x2{(float)h0[1], (float)h1[1]};
+    mid[0] = cvt_pk_f16(a[0], b[0]);
+    mid[1] = cvt_pk_f16(a[1], b[1]);
 }
 
-__device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                   0, 0);
+__device__ __forceinline__ f32x4 mma_f16(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
 }
 
-// acc += l^T r over the 32 entries of the tile, planes {hi, mid, lo}; smallest products first.
-__device__ __forceinline__ f32x4 mma6(f32x4 acc, const u32x4 (&l)[3], const u32x4 (&r)[3]) {
-    acc = mma_bf16(l[2], r[0], acc);
-    acc = mma_bf16(l[0], r[2], acc);
-    acc = mma_bf16(l[1], r[1], acc);
-    acc = mma_bf16(l[1], r[0], acc);
-    acc = mma_bf16(l[0], r[1], acc);
-    acc = mma_bf16(l[0], r[0], acc);
+// acc += l^T r over the 32 entries of the tile, planes {hi, mid}; smallest products first.
+__device__ __forceinline__ f32x4 mma3(f32x4 acc, const u32x4 (&l)[2], const u32x4 (&r)[2]) {
+    acc = mma_f16(l[1], r[0], acc);
+    acc = mma_f16(l[0], r[1], acc);
+    acc = mma_f16(l[0], r[0], acc);
     return acc;
 }
 
-// One LDS tile of 32 gathered rows: the wave's NB+1 tiles, six MFMAs each.  The left operands are the right
+// Power of two that puts the largest scaled entry z = sqrt(||c|-1|) y just below 2^15: |y| <= sqrt(gmax) for
+// gmax the largest diagonal entry of G = Y^T Y + reg I, ||c|-1| <= max(cmax - 1, 1).  Clamped to 2^+-40 so that
+// its inverse square stays a normal fp32 number.  Returns (scale, 1 / scale^2).
+__device__ __forceinline__ f32x2 gram_scale(float gmax, float cmax) {
+    const float wmax = fmaxf(cmax - 1.f, 1.f);
+    const float bound = sqrtf(gmax) * sqrtf(wmax);
+    int e = 0;
+    (void)frexpf(bound, &e);  // bound = m 2^e, 0.5 <= m < 1 (e = 0 for bound = 0)
+    int sh = 15 - e;
+    if (!(bound > 0.f) || sh > 40) sh = 40;
+    if (sh < -40) sh = -40;
+    return f32x2{ldexpf(1.f, sh), ldexpf(1.f, -2 * sh)};
+}
+
+// One LDS tile of 32 gathered rows: the wave's NB+1 tiles, three MFMAs each.  The left operands are the right
 // ones with the sign of every negative-weight entry flipped (a wave-uniform branch skips that for tiles
 // without such entries).
 template <int NT, int W>
@@ -382,13 +407,13 @@ __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, Wa
     using WA = WaveAcc<NT, W>;
     constexpr int N0 = WA::N0, R1 = WA::R1;
     const int m = lane & 15, q = lane >> 4;
-    const char* base = tl + m * 64 + ((q ^ ((m >> 1) & 3)) << 4);
+    const char* base = tl + C::col_row(m) * 64 + ((q ^ C::col_swz(m)) << 4);
     auto ld = [&](int band, int plane) __attribute__((always_inline)) {
         return *reinterpret_cast<const u32x4*>(base + plane * C::PLANE_BYTES + band * 1024);
     };
-    u32x4 r0[3], r1[3], l0[3], l1[3];
+    u32x4 r0[2], r1[2], l0[2], l1[2];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 2; ++p) {
         r0[p] = ld(W, p);
         r1[p] = ld(R1, p);
     }
@@ -396,13 +421,13 @@ __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, Wa
     const u32x4 sg = *reinterpret_cast<const u32x4*>(sm + 4 * q);
     const bool flip = __builtin_amdgcn_ballot_w64((sg[0] | sg[1] | sg[2] | sg[3]) != 0u) != 0ull;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 2; ++p) {
         l0[p] = r0[p];
         l1[p] = r1[p];
     }
     if (flip) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < 2; ++p) {
             l0[p] ^= sg;
             l1[p] ^= sg;
         }
@@ -410,11 +435,11 @@ __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, Wa
 #pragma unroll
     for (int j = 0; j < N0; ++j) {
         const int band = W + j;
-        u32x4 rb[3];
+        u32x4 rb[2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) rb[p] = (j == 0) ? r0[p] : (band == R1 ? r1[p] : ld(band, p));
-        A.a0[j] = mma6(A.a0[j], l0, rb);
-        if (band >= R1) A.a1[band - R1] = mma6(A.a1[band - R1], l1, rb);
+        for (int p = 0; p < 2; ++p) rb[p] = (j == 0) ? r0[p] : (band == R1 ? r1[p] : ld(band, p));
+        A.a0[j] = mma3(A.a0[j], l0, rb);
+        if (band >= R1) A.a1[band - R1] = mma3(A.a1[band - R1], l1, rb);
     }
 }
 
@@ -435,7 +460,7 @@ __device__ __forceinline__ void gram_tile(const char* tl, const uint32_t* sm, Wa
 template <int NT, bool BIG>
 __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indices, const float* __restrict__ data,
                                               const float* __restrict__ Y, int64_t ks, int64_t ke, float* smem,
-                                              int ptid) {
+                                              int ptid, float scale2) {
     using C = GramCfg<NT>;
     constexpr int F = C::F;
     char* tiles = reinterpret_cast<char*>(smem);
@@ -493,7 +518,9 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
         dp += TR;
         left_d -= TR;
     };
-    const int wbase = c2 * 128 + ((eg ^ (c2 & 3)) << 4);
+    // columns 2*c2 + t: rows 2*c2 + (t ^ ((c2 >> 1) & 1)) of a plane, chunk eg at position eg ^ swz
+    const int wswap = (c2 >> 1) & 1;
+    const int wbase = c2 * 128 + ((eg ^ C::col_swz(2 * c2)) << 4);
     unsigned long long dbg_a = 0, dbg_s[5] = {0, 0, 0, 0, 0};
     auto store_tile = [&](const f32x2 (&yv)[8], const float (&dd)[8], int buf) __attribute__((always_inline)) {
         char* tile = tiles + buf * C::TILE_BYTES;
@@ -502,7 +529,7 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             w[e] = fabsf(dd[e]) - 1.f;
-            sw[e] = __builtin_amdgcn_sqrtf(fabsf(w[e]));
+            sw[e] = __builtin_amdgcn_sqrtf(fabsf(w[e]) * scale2);  // = 2^s sqrt(|w|): scale2 = 4^s
             // max(c, 0) on the bit pattern: positive floats order like integers, everything else is <= 0
             const int di = __float_as_int(dd[e]);
             const float cp = __int_as_float(di > 0 ? di : 0);
@@ -512,24 +539,22 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
         // b is final for this tile before the next gathers overwrite yv
         asm volatile("" : "+v"(bacc0), "+v"(bacc1));
         dbg_a = DBG_T();
-        u32x4 hi[2], mid[2], lo[2];
+        u32x4 hi[2], mid[2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint32_t h[2], m[2], l[2];
-            split3x2(yv[2 * q] * sw[2 * q], yv[2 * q + 1] * sw[2 * q + 1], h, m, l);
+            uint32_t h[2], m[2];
+            split2x2(yv[2 * q] * sw[2 * q], yv[2 * q + 1] * sw[2 * q + 1], h, m);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 hi[t][q] = h[t];
                 mid[t][q] = m[t];
-                lo[t][q] = l[t];
             }
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            char* dst = tile + wbase + t * 64;
+            char* dst = tile + wbase + ((t ^ wswap) << 6);
             *reinterpret_cast<u32x4*>(dst) = hi[t];
             *reinterpret_cast<u32x4*>(dst + C::PLANE_BYTES) = mid[t];
-            *reinterpret_cast<u32x4*>(dst + 2 * C::PLANE_BYTES) = lo[t];
         }
         if (c2 == 0) {
             // sign bits of the weights of entries (2q, 2q+1) at bits 15 and 31 of word q
@@ -602,7 +627,7 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
 // producers).
 template <int NT, int W>
 __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int ntiles, float* smem, bool single,
-                                              float* P, int lane) {
+                                              float* P, int lane, float unscale) {
     using C = GramCfg<NT>;
     using WA = WaveAcc<NT, W>;
     constexpr int F = C::F;
@@ -620,7 +645,9 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
     unsigned long long dbg_w = 0, dbg_b = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
         const unsigned long long t0 = DBG_T();
+#ifndef MIREC_PROBE_NO_GRAM  // timing probe only (wrong results): the consumers skip the matrix work
         gram_tile<NT, W>(tiles + (tile & 1) * C::TILE_BYTES, smask + (tile & 1) * 16, A, lane);
+#endif
         const unsigned long long t1 = DBG_T();
         __syncthreads();
         dbg_w += t1 - t0;
@@ -643,7 +670,7 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rr = W * 16 + q * 4 + e, cc = (W + j) * 16 + i;
-                const float v = A.a0[j][e];
+                const float v = A.a0[j][e] * unscale;
                 big[rr * F + cc] = v + G[rr * F + cc];
                 if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
             }
@@ -652,7 +679,7 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rr = WA::R1 * 16 + q * 4 + e, cc = (WA::R1 + j) * 16 + i;
-                const float v = A.a1[j][e];
+                const float v = A.a1[j][e] * unscale;
                 big[rr * F + cc] = v + G[rr * F + cc];
                 if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
             }
@@ -661,11 +688,11 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
 #pragma unroll
         for (int j = 0; j < WA::N0; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) P[(C::row_start(W) + j) * 256 + (q * 4 + e) * 16 + i] = A.a0[j][e];
+            for (int e = 0; e < 4; ++e) P[(C::row_start(W) + j) * 256 + (q * 4 + e) * 16 + i] = A.a0[j][e] * unscale;
 #pragma unroll
         for (int j = 0; j < WA::N1; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) P[(C::row_start(WA::R1) + j) * 256 + (q * 4 + e) * 16 + i] = A.a1[j][e];
+            for (int e = 0; e < 4; ++e) P[(C::row_start(WA::R1) + j) * 256 + (q * 4 + e) * 16 + i] = A.a1[j][e] * unscale;
     }
 }
 
@@ -680,7 +707,8 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G,
     const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ mslot_ptr,
-    const int32_t* __restrict__ chunk_row, int cg_steps, float* partials) {
+    const int32_t* __restrict__ chunk_row, int cg_steps, float* partials, float conf_max,
+    const float* __restrict__ conf_max_dev) {
     using C = GramCfg<NT>;
     constexpr int F = C::F;
     constexpr int NTHR = 128 * NT;
@@ -719,15 +747,31 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     }
     const int ntiles = (int)((ke - ks + TR - 1) / TR);
 
-    switch (w) {
-        case 0: gram_consumer<NT, 0>(G, ntiles, smem, single, P, lane); break;
-        case 1: if constexpr (NT > 1) gram_consumer<NT, 1>(G, ntiles, smem, single, P, lane); break;
-        case 2: if constexpr (NT > 2) gram_consumer<NT, 2>(G, ntiles, smem, single, P, lane); break;
-        case 3: if constexpr (NT > 3) gram_consumer<NT, 3>(G, ntiles, smem, single, P, lane); break;
-        case 4: if constexpr (NT > 4) gram_consumer<NT, 4>(G, ntiles, smem, single, P, lane); break;
-        case 5: if constexpr (NT > 5) gram_consumer<NT, 5>(G, ntiles, smem, single, P, lane); break;
+    // the power of two that scales the fp16 operands: the same in every workgroup of every launch of a fit
+    // (it depends on the diagonal of G and on the largest confidence only)
+    f32x2 sc;
+    {
+        float gm = tid < F ? G[tid * F + tid] : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+        if (lane == 0) vec[w] = gm;
+        __syncthreads();
+        float gmax = vec[0];
+#pragma unroll
+        for (int ww = 1; ww < 2 * NT; ++ww) gmax = fmaxf(gmax, vec[ww]);
+        sc = gram_scale(gmax, conf_max > 0.f ? conf_max : *conf_max_dev);
     }
-    if (w >= NT) gram_producer<NT, BIG>(indices, data, Y, ks, ke, smem, tid - 64 * NT);
+    const float scale2 = sc[0] * sc[0], unscale = sc[1];
+
+    switch (w) {
+        case 0: gram_consumer<NT, 0>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 1: if constexpr (NT > 1) gram_consumer<NT, 1>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 2: if constexpr (NT > 2) gram_consumer<NT, 2>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 3: if constexpr (NT > 3) gram_consumer<NT, 3>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 4: if constexpr (NT > 4) gram_consumer<NT, 4>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 5: if constexpr (NT > 5) gram_consumer<NT, 5>(G, ntiles, smem, single, P, lane, unscale); break;
+    }
+    if (w >= NT) gram_producer<NT, BIG>(indices, data, Y, ks, ke, smem, tid - 64 * NT, scale2);
     __syncthreads();  // A (or the partial slot) and the b partials of the four entry groups are written
     const unsigned long long dbg_k1 = DBG_T();
     if (tid < F) {
@@ -805,11 +849,36 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
     cg_solve_block<F, NT>(big, bvec, vec, smem + C::CGP, X + (row_begin + r) * F, cg_steps, tid);
 }
 
+// Largest |confidence| over the stored entries of rows [row_begin, row_end) (non-negative floats order like their
+// bit patterns).
+__global__ __launch_bounds__(256) void conf_absmax_kernel(const float* __restrict__ data,
+                                                          const int64_t* __restrict__ indptr, int64_t row_begin,
+                                                          int64_t row_end, uint32_t* out) {
+    __shared__ uint32_t wmax[4];
+    uint32_t m = 0u;
+    const int64_t n = indptr[row_end];
+    for (int64_t i = indptr[row_begin] + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t b = __float_as_uint(data[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+        atomicMax(out, m);
+    }
+}
+
 template <int NT>
 static int launch_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                         float* X, const float* Y, const float* G, int cg_steps, const char* plan,
                         const PlanLayout& L, int32_t chunk_nnz, const int64_t counts[3], float* partials,
-                        int64_t y_rows, hipStream_t stream) {
+                        int64_t y_rows, float conf_max, const float* conf_max_dev, hipStream_t stream) {
     using S = GramCfg<NT>;
     const int32_t* chunk_ptr = (const int32_t*)(plan + L.chunk_ptr);
     const int32_t* mslot_ptr = (const int32_t*)(plan + L.mslot_ptr);
@@ -833,11 +902,11 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
         if (big)
             hipLaunchKernelGGL((als_gram_cg_kernel<NT, true>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
-                               cg_steps, partials);
+                               cg_steps, partials, conf_max, conf_max_dev);
         else
             hipLaunchKernelGGL((als_gram_cg_kernel<NT, false>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
-                               cg_steps, partials);
+                               cg_steps, partials, conf_max, conf_max_dev);
         MIREC_LAUNCH_CHECK();
     }
     if (counts[1] > 0) {
@@ -932,18 +1001,20 @@ extern "C" int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, in
     return MIREC_OK;
 }
 
+constexpr size_t SWEEP_WS_HEADER = 256;  // the largest |confidence|, when the sweep has to find it itself
+
 extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], int f) {
     if (!host_counts || f <= 0) return 0;
-    const size_t slots = host_counts[2] > 0 ? (size_t)host_counts[2] : 1;
+    const size_t slots = host_counts[2] > 0 ? (size_t)host_counts[2] : 0;
     const size_t nb = (size_t)f / 16;  // upper-triangle 16x16 tiles + the b vector (GramCfg::PART_STRIDE)
-    return slots * (nb * (nb + 1) / 2 * 256 + f) * sizeof(float);
+    return SWEEP_WS_HEADER + slots * (nb * (nb + 1) / 2 * 256 + f) * sizeof(float);
 }
 
 extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data,
                                     int64_t row_begin, int64_t row_end, int64_t nnz, float* X, const float* Y,
                                     int64_t y_rows, const float* G, int f, int cg_steps, const void* plan, int32_t chunk_nnz,
-                                    int32_t short_max, const int64_t host_counts[4], void* ws, size_t ws_bytes,
-                                    mirec_stream_t stream_) {
+                                    int32_t short_max, const int64_t host_counts[4], float conf_max, void* ws,
+                                    size_t ws_bytes, mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (row_end == row_begin) return MIREC_OK;  // a shard without rows (its X block may be a null pointer)
     MIREC_REQUIRE(indptr && X && Y && G && plan && host_counts, MIREC_E_INVALID, "mirec_als_half_sweep: null argument");
@@ -954,14 +1025,28 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     MIREC_REQUIRE(chunk_nnz > 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad chunk_nnz %d", chunk_nnz);
     MIREC_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, MIREC_E_INVALID,
                   "mirec_als_half_sweep: factor matrices must be 16-byte aligned");
-    MIREC_REQUIRE(host_counts[2] == 0 || (ws && ws_bytes >= mirec_als_sweep_workspace_bytes(host_counts, f)),
+    MIREC_REQUIRE(host_counts[0] == 0 || (ws && ws_bytes >= mirec_als_sweep_workspace_bytes(host_counts, f)),
                   MIREC_E_WORKSPACE, "mirec_als_half_sweep: workspace of %zu bytes needed, %zu given",
                   mirec_als_sweep_workspace_bytes(host_counts, f), ws_bytes);
+    MIREC_REQUIRE(conf_max >= 0.f || conf_max != conf_max, MIREC_E_INVALID,
+                  "mirec_als_half_sweep: conf_max must be the largest |confidence| (or 0: not known)");
     const int64_t nrows = row_end - row_begin;
     if (nrows == 0) return MIREC_OK;
     const PlanLayout L = plan_layout(nrows, nnz, chunk_nnz);
     const char* p = (const char*)plan;
-    float* partials = (float*)ws;
+    float* partials = ws ? (float*)((char*)ws + SWEEP_WS_HEADER) : nullptr;
+    const float* conf_max_dev = (const float*)ws;
+    if (host_counts[0] > 0 && !(conf_max > 0.f)) {
+        // not given: one pass over the stored values of the row range (their largest magnitude bounds the
+        // fp16 operands of the explicit-Gram kernel)
+        conf_max = 0.f;
+        MIREC_HIP(hipMemsetAsync(ws, 0, SWEEP_WS_HEADER, stream));
+        if (nnz > 0) {
+            hipLaunchKernelGGL(conf_absmax_kernel, dim3(1024), dim3(256), 0, stream, data, indptr, row_begin, row_end,
+                               (uint32_t*)ws);
+            MIREC_LAUNCH_CHECK();
+        }
+    }
     if (short_max >= 0 && host_counts[3] > 0) {
         const int rc = launch_als_short(f / 32, y_rows, indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps,
                                         (const int32_t*)(p + L.short_order), host_counts[3], stream);
@@ -969,12 +1054,12 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     }
     if (host_counts[0] == 0 && host_counts[1] == 0) return MIREC_OK;
     switch (f / 32) {
-        case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
-        case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
-        case 3: return launch_sweep<3>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
-        case 4: return launch_sweep<4>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
-        case 5: return launch_sweep<5>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
-        case 6: return launch_sweep<6>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, stream);
+        case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
+        case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
+        case 3: return launch_sweep<3>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
+        case 4: return launch_sweep<4>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
+        case 5: return launch_sweep<5>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
+        case 6: return launch_sweep<6>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
     }
     return MIREC_E_UNSUPPORTED;
 }

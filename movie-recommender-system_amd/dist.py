@@ -130,6 +130,18 @@ def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def allreduce_max(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Maximum over the ranks (through host memory when the backend cannot take the tensor's device)."""
+    if dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and not _is_nccl(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def alltoallv(send: Sequence[torch.Tensor], group=None) -> List[torch.Tensor]:
     """Rank r's ``send[d]`` (1-D, any length) arrives as element r of the list rank d gets back.  One
     all-to-all on RCCL; pairwise sends on other backends (through host memory for device tensors)."""
@@ -317,9 +329,16 @@ def gpu_driver(Cui, Ciu, X: torch.Tensor, Y: torch.Tensor, regularization: float
         ciu_local, ib = shard_item_rows(shards, users, n_items, rank, group)
     Xpad = torch.zeros((users.padded, X.shape[1]), dtype=X.dtype, device=X.device)
     Xpad[:users.nrows].copy_(X)
+    # the largest |confidence| of the whole matrix: every rank scales the matrix-core operands alike
+    cmax = torch.zeros(1, dtype=torch.float32, device=X.device)
+    for _, _, c in shards:
+        if c.nnz:
+            cmax = torch.maximum(cmax, c.data.abs().max().reshape(1))
+    if world > 1:
+        cmax = allreduce_max(cmax, group)
     eng = E.AlsEngine(None, None, Xpad[:users.nrows], Y, regularization, cg_steps, user_blocks=users.owned(rank),
                       item_rows=(ib[rank], ib[rank + 1]), chunk_nnz=chunk_nnz, short_max=short_max,
-                      user_shards=[c for _, _, c in shards], item_shard=ciu_local)
+                      user_shards=[c for _, _, c in shards], item_shard=ciu_local, conf_max=float(cmax.item()))
     # The driver walks this rank's blocks in order and skips those without rows; block 0 (which refreshes the
     # Gram of Y) is empty only if all of the rank's blocks are, since later slabs hold higher rows.
     index_of = {blk: j for j, blk in enumerate(eng.user_blocks) if blk[1] > blk[0]}

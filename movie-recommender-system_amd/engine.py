@@ -168,9 +168,14 @@ class SweepPlan:
     matrix-free wave-per-row kernel, the others by the explicit-Gram kernel
     (None = choose from the size of the gathered table)."""
 
-    def __init__(self, csr: DeviceCSR, f: int, chunk_nnz: int = 0, short_max: Optional[int] = None):
+    def __init__(self, csr: DeviceCSR, f: int, chunk_nnz: int = 0, short_max: Optional[int] = None,
+                 conf_max: float = 0.0):
+        """``conf_max``: the largest |confidence| of the whole matrix (0 = let every sweep find its own
+        rows' with one pass over their values); it fixes the power of two that scales the explicit-Gram
+        kernel's fp16 operands, so ranks of a sharded fit should all pass the matrix-wide value."""
         lib = _lib.require()
         self.csr, self.f = csr, int(f)
+        self.conf_max = float(conf_max)
         nrows = csr.shape[0]
         dev = csr.indptr.device
         if short_max is None:
@@ -229,8 +234,8 @@ class SweepPlan:
                 short_max = -1
         _lib.check(lib.mirec_als_half_sweep(_ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.data), 0, csr.shape[0],
                                             csr.nnz, _ptr(X_rows), _ptr(Y), int(Y.shape[0] if y_rows is None else y_rows), _ptr(G), self.f, int(cg_steps),
-                                            _ptr(self.plan), self.chunk_nnz, short_max, counts, _ptr(self.ws),
-                                            self.ws.numel(), _stream_ptr()), "mirec_als_half_sweep")
+                                            _ptr(self.plan), self.chunk_nnz, short_max, counts, self.conf_max,
+                                            _ptr(self.ws), self.ws.numel(), _stream_ptr()), "mirec_als_half_sweep")
 
 
 class AlsEngine:
@@ -245,7 +250,8 @@ class AlsEngine:
                  regularization: float, cg_steps: int = 3,
                  user_blocks: Optional[Sequence[Tuple[int, int]]] = None,
                  item_rows: Optional[Tuple[int, int]] = None, chunk_nnz: int = 0, short_max: Optional[int] = None,
-                 user_shards: Optional[Sequence[DeviceCSR]] = None, item_shard: Optional[DeviceCSR] = None):
+                 user_shards: Optional[Sequence[DeviceCSR]] = None, item_shard: Optional[DeviceCSR] = None,
+                 conf_max: Optional[float] = None):
         """``Cui`` / ``Ciu``: the whole matrix and its transpose (``Ciu`` None: transposed here), sliced to
         ``user_blocks`` / ``item_rows``.  A rank that holds only its share passes instead ``user_shards`` (one
         CSR per entry of ``user_blocks``, rows [a, b) of the matrix) and ``item_shard`` (rows ``item_rows`` of
@@ -265,13 +271,17 @@ class AlsEngine:
                 Ciu = Cui.transpose()
             item_shard = Ciu if self.item_rows == (0, items) else Ciu.row_slice(*self.item_rows)
         assert len(user_shards) == len(self.user_blocks)
+        if conf_max is None:
+            # the largest |confidence| of what this engine holds (the whole matrix, unless a sharded driver says otherwise)
+            conf_max = max([float(m.data.abs().max()) for m in list(user_shards) + [item_shard] if m.nnz] + [0.0])
+        self.conf_max = float(conf_max)
         self.plans_u = []
         for (a, b), cu in zip(self.user_blocks, user_shards):
             assert cu.shape == (b - a, items), "a user shard must hold exactly the rows of its block"
-            self.plans_u.append(SweepPlan(cu, self.f, chunk_nnz, short_max) if b > a else None)
+            self.plans_u.append(SweepPlan(cu, self.f, chunk_nnz, short_max, self.conf_max) if b > a else None)
         assert item_shard.shape == (self.item_rows[1] - self.item_rows[0], users)
         self.Ciu_local = item_shard
-        self.plan_i = SweepPlan(item_shard, self.f, chunk_nnz, short_max)
+        self.plan_i = SweepPlan(item_shard, self.f, chunk_nnz, short_max, self.conf_max)
         lib = _lib.require()
         need = max(lib.mirec_gram_workspace_bytes(users, self.f), lib.mirec_gram_workspace_bytes(items, self.f))
         self.gram_ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=X.device)
