@@ -1,7 +1,9 @@
 """Per-tile trace of one workgroup of the bf16-plane top-K kernel (library built with -DMIREC_DEBUG_TIMING)."""
 import ctypes, sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from movie_recommender_system_amd import engine as E, synth, _lib
+from movie_recommender_system_amd import _lib
+_lib.load(os.environ.get("MIREC_LIB", _lib.LIB_PATH))
+from movie_recommender_system_amd import engine as E, synth
 dev = torch.device("cuda", 0)
 U, I, F = 1_000_000, 27_000, 128
 indptr, indices, data = synth.interactions_torch(42, U, I, 50.0, dev)
