@@ -10,9 +10,9 @@ N > 1, both all-gathers).  The problem size is fixed as N grows (strong
 scaling): users and items are sharded across the ranks by stored entries.
 
 Rank 0 prints ONE JSON line.  `value` is seconds per ALS iteration (max over
-ranks, inputs resident in HBM).  `roofline` describes the dominant kernel
-(als_gram_cg_kernel): algorithmic bytes per launch / live HIP-event time per
-launch against the 8 TB/s HBM peak.  `cpu_baseline` times the CPU oracle (a
+ranks, inputs resident in HBM).  `roofline` describes the dominant kernel (the
+half-sweep kernel with the larger time per iteration): algorithmic bytes per
+launch / live HIP-event time per launch against the 8 TB/s HBM peak.  `cpu_baseline` times the CPU oracle (a
 restatement of implicit 0.7.2's CG solver) on a bounded sample of the same
 matrix on the host cores.  `extra` carries the top-20 pass (users/s, fp32 MFMA
 roofline) and the per-kernel times.
@@ -262,7 +262,9 @@ def main():
         (rs, ns), (rm, nm) = split_by_kernel(plans)
         # algorithmic bytes of the rows each kernel solved
         if c_s:
-            out.append(("als_short_kernel", sweep_bytes(ns, rs, F), t_s / args.steps, c_s))
+            # widths 64 and 128 run the variant whose G v products are evaluated on the matrix cores
+            out.append(("als_short_mfma_kernel" if F in (64, 128) else "als_short_kernel", sweep_bytes(ns, rs, F),
+                        t_s / args.steps, c_s))
         if c_m:
             out.append(("als_gram_cg_kernel", sweep_bytes(nm, rm, F), t_m / args.steps, c_m))
         return out

@@ -180,13 +180,13 @@ class SweepPlan:
         dev = csr.indptr.device
         if short_max is None:
             table_bytes = csr.shape[1] * self.f * 4
-            # Measured at f = 128 (tools/microbench.py sweep --short-max): with the gathered table on chip (L2 /
-            # Infinity Cache) the matrix-free kernel wins up to about a thousand entries per row; with a larger
-            # table its four passes of gathers cost more, and the explicit Gram takes over from about 256 -- but
-            # rows of a few dozen entries stay far cheaper matrix-free whatever the table (2 M users x 60 entries
-            # against a 102 MB / 410 MB table: 18.7 / 21.1 ms, against 49 / 50 ms through the Gram kernel).
+            # Measured at f = 128 (tools/probes/short_max_sweep.sh): with the gathered table on chip (L2 /
+            # Infinity Cache; 1 M users x 27 k items) the user half-sweep takes 14.6 / 9.7 / 7.3 / 6.4 / 6.3 / 6.4 ms
+            # for limits of 32 / 64 / 128 / 256 / 512 / 1024 entries; with a larger table (2 M users x 200 k items,
+            # 102 MB, mean 187 entries) the four passes of gathers cost more and the explicit Gram takes over
+            # earlier: 60.7 / 52.3 / 48.4 / 51.7 / 57.0 ms for 64 / 128 / 256 / 512 / 1024.
             # The Gram's cost per entry grows with f^2, a gather's with f: the limits scale with f.
-            limit = 1024 if table_bytes <= SHORT_TABLE_BYTES else 256
+            limit = 512 if table_bytes <= SHORT_TABLE_BYTES else 256
             short_max = max(limit * self.f // 128, int(lib.mirec_als_short_cache_rows(self.f)), 32)
         self.short_max = int(short_max)
         nbytes = lib.mirec_als_plan_bytes(nrows, csr.nnz, int(chunk_nnz))
