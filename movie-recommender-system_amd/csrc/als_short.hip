@@ -182,42 +182,11 @@ __device__ __forceinline__ const float* gather_ptr(const float* Y, int sel, int 
     }
 }
 
-// One step of a pass: stored entries [g0, g0 + 16), half h taking entry g0 + 2j + h as its j-th.  Entries
-// past the end of the row repeat the row's last entry (always loadable) and get coefficient zero, so no
-// load is conditional.  MODE 0: every entry slot of the step lies inside this wave's on-chip cache,
-// 1: the step straddles the end of the cache (g0 is then a compile-time constant), 2: it lies past it.
-// GVN = 8: a full step; GVN = 4: the half step that ends a row with at most 8 entries left (entries
-// [g0, g0 + 8), the same assignment to halves and cache slots, half the gathers and arithmetic).
-template <int NT, int CAP, bool FIRST, bool BIG, int MODE, int GVN = GV>
-__device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[NT], const float* __restrict__ Y,
-                                            float* cache, int g0, int n, int cur_sel, float cur_dat, int selbase,
-                                            int coefbase, int h, int c) {
-    constexpr int F = 32 * NT;
-    constexpr int G0C = (CAP / STEP) * STEP;
-    float yv[GVN][NT];
-    int sel[GVN];
-    float* slot = cache + (g0 + h) * F + c * NT;
-#pragma unroll
-    for (int j = 0; j < GVN; ++j) {
-        const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
-        if (FIRST || !inside) sel[j] = __builtin_amdgcn_ds_bpermute(selbase + 8 * j, cur_sel);
-    }
-#pragma unroll
-    for (int j = 0; j < GVN; ++j) {
-        const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
-        if (FIRST || !inside) {
-            load_n<NT>(yv[j], gather_ptr<NT, BIG>(Y, sel[j], c));
-        } else {
-            load_n<NT>(yv[j], slot + 2 * j * F);
-        }
-    }
-    if constexpr (FIRST) {
-#pragma unroll
-        for (int j = 0; j < GVN; ++j) {
-            const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
-            if (inside) store_n<NT>(slot + 2 * j * F, yv[j]);
-        }
-    }
+// The arithmetic of a step on the gathered rows yv[0 .. GVN): the dot products with v, their reduction, the
+// coefficients and the update of acc.
+template <int NT, bool FIRST, int GVN>
+__device__ __forceinline__ void step_math(const float (&yv)[GV][NT], const float (&v)[NT], float (&acc)[NT], int g0,
+                                          int n, float cur_dat, int coefbase, int h, int c) {
 #ifdef MIREC_PROBE_LOADS_ONLY  // timing probe only (wrong results): the gathers and cache traffic without the arithmetic
 #pragma unroll
     for (int j = 0; j < GVN; ++j)
@@ -253,15 +222,79 @@ __device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[N
     }
 }
 
+// One step of a pass: stored entries [g0, g0 + 16), half h taking entry g0 + 2j + h as its j-th.  Entries
+// past the end of the row repeat the row's last entry (always loadable) and get coefficient zero, so no
+// load is conditional.  MODE 0: every entry slot of the step lies inside this wave's on-chip cache,
+// 1: the step straddles the end of the cache (gc is then a compile-time constant), 2: it lies past it.
+// gc = position of the step in the cache (the cache may start at a later entry than the row).
+// GVN = 8: a full step; GVN = 4: the half step that ends a row with at most 8 entries left (entries
+// [g0, g0 + 8), the same assignment to halves and cache slots, half the gathers and arithmetic).
+template <int NT, int CAP, bool FIRST, bool BIG, int MODE, int GVN = GV>
+__device__ __forceinline__ void sparse_step(const float (&v)[NT], float (&acc)[NT], const float* __restrict__ Y,
+                                            float* cache, int g0, int n, int cur_sel, float cur_dat, int selbase,
+                                            int coefbase, int h, int c, int gc) {
+    constexpr int F = 32 * NT;
+    constexpr int G0C = (CAP / STEP) * STEP;
+    float yv[GV][NT];
+    int sel[GVN];
+    float* slot = cache + (gc + h) * F + c * NT;
+#pragma unroll
+    for (int j = 0; j < GVN; ++j) {
+        const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
+        if (FIRST || !inside) sel[j] = __builtin_amdgcn_ds_bpermute(selbase + 8 * j, cur_sel);
+    }
+#pragma unroll
+    for (int j = 0; j < GVN; ++j) {
+        const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
+        if (FIRST || !inside) {
+            load_n<NT>(yv[j], gather_ptr<NT, BIG>(Y, sel[j], c));
+        } else {
+            load_n<NT>(yv[j], slot + 2 * j * F);
+        }
+    }
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int j = 0; j < GVN; ++j) {
+            const bool inside = MODE == 0 || (MODE == 1 && G0C + 2 * j < CAP);
+            if (inside) store_n<NT>(slot + 2 * j * F, yv[j]);
+        }
+    }
+    step_math<NT, FIRST, GVN>(yv, v, acc, g0, n, cur_dat, coefbase, h, c);
+}
+
+// The same step on rows that stay in registers for all passes of a CSR row: the first pass gathers them into
+// R, the later ones only do the arithmetic.
+template <int NT, bool FIRST, bool BIG, int GVN>
+__device__ __forceinline__ void reg_step(float (&R)[GV][NT], const float (&v)[NT], float (&acc)[NT],
+                                         const float* __restrict__ Y, int g0, int n, int cur_sel, float cur_dat,
+                                         int selbase, int coefbase, int h, int c) {
+    if constexpr (FIRST) {
+        int sel[GVN];
+#pragma unroll
+        for (int j = 0; j < GVN; ++j) sel[j] = __builtin_amdgcn_ds_bpermute(selbase + 8 * j, cur_sel);
+#pragma unroll
+        for (int j = 0; j < GVN; ++j) load_n<NT>(R[j], gather_ptr<NT, BIG>(Y, sel[j], c));
+        // every register of R is written in the first pass of a CSR row (the later passes read the same ones,
+        // which the compiler cannot see: left unwritten they would count as carried over from the previous row)
+#pragma unroll
+        for (int j = GVN; j < GV; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) R[j][t] = 0.f;
+    }
+    step_math<NT, FIRST, GVN>(R, v, acc, g0, n, cur_dat, coefbase, h, c);
+}
+
 // acc (in every lane: the sum over all the row's stored entries) of
 //   FIRST:  (max(c,0) - (|c|-1)(y.v)) y        (start residual, v = x)
 //   else :  (|c|-1)(y.v) y                     (operator, v = p)
 // Lane l keeps, one step ahead, the index of entry g0 + (l & 15) and the confidence of the entry whose dot
 // product the reduction leaves in it.
-template <int NT, int CAP, bool FIRST, bool BIG>
+// RS: the first RS steps of the row work on rows held in registers (R, RS * 8 rows per half-wave); the cache
+// then starts at entry RS * 16 of the row.
+template <int NT, int CAP, bool FIRST, bool BIG, int RS = 0>
 __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[NT], const int32_t* __restrict__ indices,
                                             const float* __restrict__ data, const float* __restrict__ Y, float* cache,
-                                            int n, int lane, int h, int c) {
+                                            int n, int lane, int h, int c, float (*R)[GV][NT] = nullptr) {
     constexpr int F = 32 * NT;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
@@ -287,7 +320,27 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
     };
     int nxt_sel = load_sel(0);
     float nxt_dat = load_dat(0);
-    for (int g0 = 0; g0 < n; g0 += STEP) {
+    constexpr int GR = RS * STEP;  // entries of the row that live in registers
+#pragma unroll
+    for (int sidx = 0; sidx < RS; ++sidx) {
+        const int g0 = sidx * STEP;
+        if (g0 < n) {
+            const int cur_sel = BIG ? nxt_sel : (int)((uint32_t)nxt_sel * (uint32_t)(F * 4));
+            const float cur_dat = nxt_dat;
+            if (g0 + STEP < n) {
+                nxt_sel = load_sel(g0 + STEP);
+                nxt_dat = load_dat(g0 + STEP);
+            }
+            if (n - g0 <= GV) reg_step<NT, FIRST, BIG, GV / 2>(R[sidx], v, acc, Y, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+            else reg_step<NT, FIRST, BIG, GV>(R[sidx], v, acc, Y, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+        } else if constexpr (FIRST) {
+#pragma unroll
+            for (int j = 0; j < GV; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) R[sidx][j][t] = 0.f;
+        }
+    }
+    for (int g0 = GR; g0 < n; g0 += STEP) {
         // scaled to a byte offset only now, so that the load above stays in flight through the previous step
         const int cur_sel = BIG ? nxt_sel : (int)((uint32_t)nxt_sel * (uint32_t)(F * 4));
         const float cur_dat = nxt_dat;
@@ -295,24 +348,25 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
             nxt_sel = load_sel(g0 + STEP);
             nxt_dat = load_dat(g0 + STEP);
         }
+        const int gc = g0 - GR;
         if (n - g0 <= GV) {
-            if (g0 + GV <= CAP) {
-                sparse_step<NT, CAP, FIRST, BIG, 0, GV / 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
-            } else if (CAP % STEP == 0 || g0 >= CAP) {
-                sparse_step<NT, CAP, FIRST, BIG, 2, GV / 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+            if (gc + GV <= CAP) {
+                sparse_step<NT, CAP, FIRST, BIG, 0, GV / 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c, gc);
+            } else if (CAP % STEP == 0 || gc >= CAP) {
+                sparse_step<NT, CAP, FIRST, BIG, 2, GV / 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c, gc);
             } else {
                 if constexpr (CAP % STEP != 0)
-                    sparse_step<NT, CAP, FIRST, BIG, 1, GV / 2>(v, acc, Y, cache, (CAP / STEP) * STEP, n, cur_sel, cur_dat,
-                                                                selbase, coefbase, h, c);
+                    sparse_step<NT, CAP, FIRST, BIG, 1, GV / 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase,
+                                                                coefbase, h, c, (CAP / STEP) * STEP);
             }
-        } else if (g0 + STEP <= CAP) {
-            sparse_step<NT, CAP, FIRST, BIG, 0>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
-        } else if (CAP % STEP == 0 || g0 >= CAP) {
-            sparse_step<NT, CAP, FIRST, BIG, 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c);
+        } else if (gc + STEP <= CAP) {
+            sparse_step<NT, CAP, FIRST, BIG, 0>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c, gc);
+        } else if (CAP % STEP == 0 || gc >= CAP) {
+            sparse_step<NT, CAP, FIRST, BIG, 2>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c, gc);
         } else {
             if constexpr (CAP % STEP != 0)
-                sparse_step<NT, CAP, FIRST, BIG, 1>(v, acc, Y, cache, (CAP / STEP) * STEP, n, cur_sel, cur_dat, selbase,
-                                                    coefbase, h, c);
+                sparse_step<NT, CAP, FIRST, BIG, 1>(v, acc, Y, cache, g0, n, cur_sel, cur_dat, selbase, coefbase, h, c,
+                                                    (CAP / STEP) * STEP);
         }
     }
 #pragma unroll
@@ -441,46 +495,61 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
 // On the vector ALU a product costs F*F/64 fused multiply-adds per lane and a read of all of G from LDS, per
 // row; with the gathers hidden that was a third of the kernel.  A matrix-vector product does not fill a matrix
 // instruction, several of them do.  The workgroup therefore has two kinds of wavefronts:
-//   NS = 12 solvers   each with a row of its own, through the same passes as above, but where the vector
-//                     kernel multiplies by G they PUBLISH the vector -- three bf16 planes (v = hi + mid + lo
-//                     exactly, as the explicit-Gram kernel splits its rows) into their row of an LDS image,
-//                     then a sequence number -- run the pass over the gathered rows (the product is not
-//                     needed before its end) and COLLECT the product from LDS;
-//   4 servers         one per SIMD, each holding a quarter of G as split bf16 fragments in registers.  A
-//                     server polls the sequence numbers, and for the vectors that are waiting evaluates its
-//                     bands of G times all of them with v_mfma_f32_16x16x32_bf16 (six plane products per
-//                     k step, the smallest first: fp32 accuracy), stores the columns that were waiting and
-//                     counts them done.
+//   NS = 10 solvers   each with a row of its own, through the same passes as above, but where the vector
+//                     kernel multiplies by G they PUBLISH the vector -- scaled by a power of two and split
+//                     into two fp16 planes (v = hi + mid to 22 bits, as the explicit-Gram kernel splits its
+//                     rows) into their row of an LDS image, then a sequence number -- run the pass over the
+//                     gathered rows (the product is not needed before its end) and COLLECT the product;
+//   2 servers         each holding half of G as scaled fp16 fragments in registers.  A server polls the
+//                     sequence numbers, and once the vectors wait evaluates its bands of G times all of
+//                     them with v_mfma_f32_16x16x32_f16 (three plane products per k step, the smallest
+//                     first), stores the columns that were waiting and counts them done.
 // Nobody waits at a barrier: a solver waits only for its own product, which the servers evaluate while it is
-// busy with its pass, so solvers keep hiding each other's memory latency as before.  G is no longer held in LDS, so the row caches grow.  A column
-// of a product depends on its vector only, so a row's result does not depend on what else was in flight.
-typedef __attribute__((ext_vector_type(8))) __bf16 sm_bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 sm_bf16x2;
+// busy with its pass, so solvers keep hiding each other's memory latency as before.  A column of a product
+// depends on its vector only, so a row's result does not depend on what else was in flight.
+// With G out of LDS and twelve wavefronts of 168 registers, a solver keeps the first 16 * RS gathered rows of
+// its CSR row in registers and the next CAP in LDS for all four passes: rows of up to 16 * RS + CAP entries are
+// gathered once.  Measured on the 1 M x 27 k user half-sweep (F = 128): RS = 1 6.17 ms, RS = 2 7.0 ms (the
+// second set of registers spills), sixteen wavefronts of 128 registers with bf16 planes and no rows in
+// registers 6.34 ms.
+typedef __attribute__((ext_vector_type(8))) _Float16 sm_f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 sm_f16x2;
 typedef __attribute__((ext_vector_type(2))) float sm_f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t sm_u32x4;
 
 __device__ __forceinline__ uint32_t sm_cvt_pk(float a, float b) {
     const sm_f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sm_bf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sm_f16x2));
 }
 
-// (a, b) -> packed bf16 pairs (a in the low half) with hi + mid + lo == value to 24 bits: round to nearest at
-// every level, every remainder exact in fp32.
-__device__ __forceinline__ void sm_split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+// (a, b) -> packed fp16 pairs (a in the low half) with hi + mid == value to 22 bits: round to nearest at both
+// levels, the remainder exact in fp32.
+__device__ __forceinline__ void sm_split2(float a, float b, uint32_t& hi, uint32_t& mid) {
     hi = sm_cvt_pk(a, b);
-    a -= __uint_as_float(hi << 16);
-    b -= __uint_as_float(hi & 0xffff0000u);
+    const sm_f16x2 hv = __builtin_bit_cast(sm_f16x2, hi);
+    a -= (float)hv[0];
+    b -= (float)hv[1];
     mid = sm_cvt_pk(a, b);
-    a -= __uint_as_float(mid << 16);
-    b -= __uint_as_float(mid & 0xffff0000u);
-    lo = sm_cvt_pk(a, b);
 }
 
 __device__ __forceinline__ f32x4 sm_mma(const sm_u32x4& a, const sm_u32x4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sm_bf16x8, a), __builtin_bit_cast(sm_bf16x8, b), c,
-                                                   0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sm_f16x8, a), __builtin_bit_cast(sm_f16x8, b), c,
+                                                  0, 0, 0);
 }
 
+// Power of two 2^s with bound * 2^s < 2^15 for any finite bound (|values| <= bound then fit fp16 and those that
+// matter are normal numbers), as (2^s, 2^-s).  s is kept within [-113, 73] so that both are normal fp32 numbers.
+__device__ __forceinline__ sm_f32x2 sm_scale_for(float bound) {
+    int e = (int)((__float_as_uint(bound) >> 23) & 0xffu);   // biased exponent: bound < 2^(e - 126)
+    int se = 268 - e;                                         // biased exponent of 2^(14 - (e - 127))
+    se = se > 200 ? 200 : se;
+    return sm_f32x2{__uint_as_float((uint32_t)se << 23), __uint_as_float((uint32_t)(254 - se) << 23)};
+}
+
+// Steps (of 16 stored entries) of a CSR row whose gathered rows stay in registers.
+#ifndef MIREC_SHORT_RS
+#define MIREC_SHORT_RS 1
+#endif
 // A server starts a sweep when every solver that still has rows has published, or after this many polls with at
 // least one vector waiting (a bound, so that the loop ends whatever the solvers do; with it reached the sweep
 // serves those that wait -- any split of the vectors over sweeps gives the same results).
@@ -492,10 +561,11 @@ template <int NT>
 struct MfmaShort {
     static_assert(NT == 2 || NT == 4, "matrix-core G v: widths 64 and 128");
     static constexpr int F = 32 * NT;
-    static constexpr int NW = 16;               // wavefronts of the workgroup
-    static constexpr int NSRV = 4;              // servers (the last wavefronts: one per SIMD)
+    static constexpr int NW = 12;               // wavefronts of the workgroup: three per SIMD, 168 registers each
+    static constexpr int NSRV = 2;              // servers (the last wavefronts)
     static constexpr int NS = NW - NSRV;        // solvers
     static constexpr int COLS = 16;             // columns of a matrix instruction (NS of them used)
+    static constexpr int RS = MIREC_SHORT_RS;   // steps of a CSR row whose gathered rows stay in registers
     static constexpr int TILES = F / 16;        // 16-row bands of G
     static constexpr int KP = 2;                // parts of the k range
     static constexpr int KSU = (F / 32) / KP;   // 32-wide k steps per part
@@ -505,10 +575,10 @@ struct MfmaShort {
     static constexpr int ROWB = 2 * F;          // bytes of a plane row
     static constexpr int PLANE_FLOATS = COLS * ROWB / 4;
     static constexpr int PART_ROW = F + 4;      // floats; the odd number of 16-byte chunks spreads the stores over the banks
-    // LDS map (floats): flags; three planes of the vectors; the partial products [KP][COLS][PART_ROW]; row caches
+    // LDS map (floats): flags; two planes of the vectors; the partial products [KP][COLS][PART_ROW]; row caches
     static constexpr int FLAGS = 0;             // int pub[16], int done[16], int finished
     static constexpr int VPL = 64;
-    static constexpr int PART = VPL + 3 * PLANE_FLOATS;
+    static constexpr int PART = VPL + 2 * PLANE_FLOATS;
     static constexpr int CACHE = PART + KP * COLS * PART_ROW;
     static constexpr int TOTAL = 160 * 1024 / 4;
     static constexpr int CAP_RAW = (TOTAL - CACHE) / (NS * F);
@@ -527,42 +597,57 @@ __device__ __forceinline__ void lds_store_release(int* p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Solver k: vector v -> row k of the three planes, then the sequence number `seq` of this product.
+// Largest diagonal entry of G (it bounds every |G_ij| of the positive semi-definite G), in every lane.
+template <int F>
+__device__ __forceinline__ float sm_gmax(const float* __restrict__ G, int lane) {
+    float g = 0.f;
+#pragma unroll
+    for (int i = lane; i < F; i += 64) g = fmaxf(g, G[i * F + i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g = fmaxf(g, __shfl_xor(g, off, 64));
+    return g;
+}
+
+// Solver k: vector v, every |v_i| <= bound -> row k of the two planes (scaled by the power of two the bound gives),
+// then the sequence number `seq` of this product.  Returns the factor that takes the collected sums back.
 template <int NT>
-__device__ __forceinline__ void symv_publish(float* smem, const float (&v)[NT], int k, int seq, int lane, int h, int c) {
+__device__ __forceinline__ float symv_publish(float* smem, const float (&v)[NT], float bound, int k, int seq, int lane,
+                                              int h, int c) {
     using M = MfmaShort<NT>;
 #ifdef MIREC_PROBE_NO_SYMV
-    return;
+    return 1.f;
 #endif
     char* vpl = reinterpret_cast<char*>(smem + M::VPL);
     constexpr int PLANEB = M::PLANE_FLOATS * 4;
+    const sm_f32x2 sc = sm_scale_for(bound);
     // lane c holds columns c*NT .. c*NT + NT-1; the two halves hold the same values
     if (h == 0) {
         if constexpr (NT == 4) {
-            uint32_t hi[2], mid[2], lo[2];
-            sm_split3(v[0], v[1], hi[0], mid[0], lo[0]);
-            sm_split3(v[2], v[3], hi[1], mid[1], lo[1]);
+            uint32_t hi[2], mid[2];
+            sm_split2(v[0] * sc[0], v[1] * sc[0], hi[0], mid[0]);
+            sm_split2(v[2] * sc[0], v[3] * sc[0], hi[1], mid[1]);
             char* dst = vpl + k * M::ROWB + (((c >> 1) ^ M::swz(k)) << 4) + ((c & 1) << 3);
             *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
             *reinterpret_cast<uint2*>(dst + PLANEB) = make_uint2(mid[0], mid[1]);
-            *reinterpret_cast<uint2*>(dst + 2 * PLANEB) = make_uint2(lo[0], lo[1]);
         } else {
-            uint32_t hi, mid, lo;
-            sm_split3(v[0], v[1], hi, mid, lo);
+            uint32_t hi, mid;
+            sm_split2(v[0] * sc[0], v[1] * sc[0], hi, mid);
             char* dst = vpl + k * M::ROWB + (((c >> 2) ^ M::swz(k)) << 4) + ((c & 3) << 2);
             *reinterpret_cast<uint32_t*>(dst) = hi;
             *reinterpret_cast<uint32_t*>(dst + PLANEB) = mid;
-            *reinterpret_cast<uint32_t*>(dst + 2 * PLANEB) = lo;
         }
     }
     // the release orders the plane stores of the whole wavefront (one instruction stream) before the number
     int* pub = reinterpret_cast<int*>(smem + M::FLAGS);
     if (lane == 0) lds_store_release(pub + k, seq);
+    return sc[1];
 }
 
-// Solver k: wait until all servers have counted product `seq` of this solver done, then out = G v.
+// Solver k: wait until all servers have counted product `seq` of this solver done, then out = G v
+// (unscale = the factor symv_publish returned times the inverse of the scale of G).
 template <int NT>
-__device__ __forceinline__ void symv_collect(float* smem, const float (&v)[NT], float (&out)[NT], int k, int seq, int c) {
+__device__ __forceinline__ void symv_collect(float* smem, const float (&v)[NT], float (&out)[NT], float unscale, int k,
+                                             int seq, int c) {
     using M = MfmaShort<NT>;
 #ifdef MIREC_PROBE_NO_SYMV
 #pragma unroll
@@ -579,18 +664,18 @@ __device__ __forceinline__ void symv_collect(float* smem, const float (&v)[NT], 
     load_n<NT>(a0, p0);
     load_n<NT>(a1, p0 + M::COLS * M::PART_ROW);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) out[t] = a0[t] + a1[t];
+    for (int t = 0; t < NT; ++t) out[t] = (a0[t] + a1[t]) * unscale;
 }
 
 // Server `srv`: until every solver has finished, evaluate its bands of G times the vectors that wait.
 template <int NT>
-__device__ __forceinline__ void symv_server(float* smem, const float* __restrict__ G, int srv, int lane) {
+__device__ __forceinline__ void symv_server(float* smem, const float* __restrict__ G, float gscale, int srv, int lane) {
     using M = MfmaShort<NT>;
     constexpr int F = M::F;
     constexpr int PLANEB = M::PLANE_FLOATS * 4;
     const int n = lane & 15, q = lane >> 4;   // operand lane: column n (a solver's vector), k group q
     // fragments of G: unit u = (band t, k part kp); rows 16t + (lane & 15), columns 32 (kp KSU + s) + 8 q .. + 7
-    sm_u32x4 Ag[M::UPS][3][M::KSU];
+    sm_u32x4 Ag[M::UPS][2][M::KSU];
 #pragma unroll
     for (int j = 0; j < M::UPS; ++j) {
         const int u = srv * M::UPS + j;
@@ -600,14 +685,13 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
             const float* g = G + (16 * t + n) * F + 32 * (kp * M::KSU + s) + 8 * q;
             const float4 g0 = *reinterpret_cast<const float4*>(g);
             const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
-            uint32_t hi[4], mid[4], lo[4];
-            sm_split3(g0.x, g0.y, hi[0], mid[0], lo[0]);
-            sm_split3(g0.z, g0.w, hi[1], mid[1], lo[1]);
-            sm_split3(g1.x, g1.y, hi[2], mid[2], lo[2]);
-            sm_split3(g1.z, g1.w, hi[3], mid[3], lo[3]);
+            uint32_t hi[4], mid[4];
+            sm_split2(g0.x * gscale, g0.y * gscale, hi[0], mid[0]);
+            sm_split2(g0.z * gscale, g0.w * gscale, hi[1], mid[1]);
+            sm_split2(g1.x * gscale, g1.y * gscale, hi[2], mid[2]);
+            sm_split2(g1.z * gscale, g1.w * gscale, hi[3], mid[3]);
             Ag[j][0][s] = sm_u32x4{hi[0], hi[1], hi[2], hi[3]};
             Ag[j][1][s] = sm_u32x4{mid[0], mid[1], mid[2], mid[3]};
-            Ag[j][2][s] = sm_u32x4{lo[0], lo[1], lo[2], lo[3]};
         }
     }
     int* flags = reinterpret_cast<int*>(smem + M::FLAGS);
@@ -620,12 +704,12 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
     int polls = 0;
     for (;;) {
         // (finished is read first: a solver publishes nothing after it has counted itself finished)
-        const bool all_finished = lds_load_acquire(finished) == M::NS;
+        const int nfin = lds_load_acquire(finished);
         const int pubv = n < M::NS ? lds_load_acquire(pub + n) : 0;
         const bool pend = pubv != seen;
         const unsigned waiting = (unsigned)__builtin_amdgcn_ballot_w64(pend) & 0xffffu;
         if (waiting == 0u) {
-            if (all_finished) break;
+            if (nfin == M::NS) break;
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
@@ -633,34 +717,33 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
         // the same time: wait until every solver that still has rows has published, and one sweep serves them
         // all.  Sweeps for one or two vectors each would cost the matrix pipe as much as a full one, and there
         // would be six times as many (measured on 1 M x 27 k users: 7.5 ms against 6.6 ms for the half-sweep).
-        {
-            const int nfin = lds_load_acquire(finished);
-            if (__builtin_popcount(waiting) < M::NS - nfin && ++polls <= MIREC_SRV_MAX_POLLS) {
-                __builtin_amdgcn_s_sleep(1);
-                continue;
-            }
+        if (__builtin_popcount(waiting) < M::NS - nfin && ++polls <= MIREC_SRV_MAX_POLLS) {
+            __builtin_amdgcn_s_sleep(1);
+            continue;
         }
         polls = 0;
 #ifndef MIREC_PROBE_NO_MFMA  // timing probe only (wrong results): the servers count products done without evaluating them
+        // the units of a server share their k part: its vector operands are read once per sweep
+        static_assert(M::UPS <= M::TILES && M::TILES % M::UPS == 0, "the units of a server lie in one k part");
+        const int kp = (srv * M::UPS) / M::TILES;
+        sm_u32x4 b[2][M::KSU];
+#pragma unroll
+        for (int s = 0; s < M::KSU; ++s) {
+            const int kc = 4 * (kp * M::KSU + s) + q;
+            const char* src = vpl + n * M::ROWB + ((kc ^ M::swz(n)) << 4);
+            b[0][s] = *reinterpret_cast<const sm_u32x4*>(src);
+            b[1][s] = *reinterpret_cast<const sm_u32x4*>(src + PLANEB);
+        }
 #pragma unroll
         for (int j = 0; j < M::UPS; ++j) {
-            const int u = srv * M::UPS + j;
-            const int t = u % M::TILES, kp = u / M::TILES;
+            const int t = (srv * M::UPS + j) % M::TILES;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < M::KSU; ++s) {
-                const int kc = 4 * (kp * M::KSU + s) + q;
-                const char* src = vpl + n * M::ROWB + ((kc ^ M::swz(n)) << 4);
-                const sm_u32x4 b0 = *reinterpret_cast<const sm_u32x4*>(src);
-                const sm_u32x4 b1 = *reinterpret_cast<const sm_u32x4*>(src + PLANEB);
-                const sm_u32x4 b2 = *reinterpret_cast<const sm_u32x4*>(src + 2 * PLANEB);
-                // smallest products first; lo*mid, mid*lo and lo*lo are below 2^-25 of the term and dropped
-                acc = sm_mma(Ag[j][2][s], b0, acc);
-                acc = sm_mma(Ag[j][0][s], b2, acc);
-                acc = sm_mma(Ag[j][1][s], b1, acc);
-                acc = sm_mma(Ag[j][1][s], b0, acc);
-                acc = sm_mma(Ag[j][0][s], b1, acc);
-                acc = sm_mma(Ag[j][0][s], b0, acc);
+                // smallest products first; mid*mid is below 2^-22 of the term and dropped
+                acc = sm_mma(Ag[j][1][s], b[0][s], acc);
+                acc = sm_mma(Ag[j][0][s], b[1][s], acc);
+                acc = sm_mma(Ag[j][0][s], b[0][s], acc);
             }
             // lane (n, q) holds rows 16t + 4q .. + 3 of G times vector n; only columns that were waiting count
             // (the others were read while their solver may have been writing them)
@@ -674,13 +757,14 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
 }
 
 template <int NT, bool BIG>
-__global__ __launch_bounds__(1024) void als_short_mfma_kernel(
+__global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G, int cg_steps,
     const int32_t* __restrict__ order, int64_t n_short) {
     using M = MfmaShort<NT>;
     constexpr int F = M::F;
     constexpr int CAP = M::CAP;
+    constexpr int RS = M::RS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -688,8 +772,10 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
     int* flags = reinterpret_cast<int*>(smem + M::FLAGS);
     if (tid < 64) flags[tid] = 0;
     __syncthreads();
+    // G enters the matrix instructions scaled by a power of two that its largest (diagonal) entry fixes
+    const sm_f32x2 gsc = sm_scale_for(sm_gmax<F>(G, lane));
     if (w >= M::NS) {
-        symv_server<NT>(smem, G, w - M::NS, lane);
+        symv_server<NT>(smem, G, gsc[0], w - M::NS, lane);
         return;
     }
     const int h = lane >> 5;
@@ -697,7 +783,7 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
     float* cache = smem + M::CACHE + w * (CAP * F);
     int seq = 0;  // products this solver has published
 
-    // the solvers of a workgroup take twelve consecutive rows of the plan's list (rows of about equal length)
+    // the solvers of a workgroup take consecutive rows of the plan's list (rows of about equal length)
     const int64_t stride = (int64_t)gridDim.x * M::NS;
     for (int64_t r = (int64_t)blockIdx.x * M::NS + w; r < n_short; r += stride) {
         const int64_t row = row_begin + order[r];
@@ -705,6 +791,7 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
         const int n = (int)(indptr[row + 1] - rs);
         float* xg = X + row * F + c * NT;
         float x[NT], rr[NT], p[NT], Ap[NT], acc[NT];
+        float R[RS][GV][NT];  // the first RS * 16 gathered rows of this CSR row (8 per half-wave and step)
         if (n == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) x[t] = 0.f;
@@ -715,10 +802,14 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
         const int32_t* ind = indices + rs;
         const float* dat = data + rs;
 
-        symv_publish<NT>(smem, x, w, ++seq, lane, h, c);
-        sparse_pass<NT, CAP, true, BIG>(x, acc, ind, dat, Y, cache, n, lane, h, c);
-        symv_collect<NT>(smem, x, Ap, w, seq, c);
+        // |x_i| <= |x|: the norm bounds the entries (a reduction per row; the CG vectors come with bounds for free)
         float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) part = fmaf(x[t], x[t], part);
+        float unscale = symv_publish<NT>(smem, x, sqrtf(half_sum(part)), w, ++seq, lane, h, c) * gsc[1];
+        sparse_pass<NT, CAP, true, BIG, RS>(x, acc, ind, dat, Y, cache, n, lane, h, c, R);
+        symv_collect<NT>(smem, x, Ap, unscale, w, seq, c);
+        part = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             rr[t] = acc[t] - Ap[t];
@@ -727,10 +818,11 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
         }
         float rsold = half_sum(part);
         if (rsold < 1e-20f) continue;
+        float pbound = sqrtf(rsold) * 1.0001f;  // |p| for p = r; afterwards |r + beta p| <= |r| + beta |p|
         for (int it = 0; it < cg_steps; ++it) {
-            symv_publish<NT>(smem, p, w, ++seq, lane, h, c);
-            sparse_pass<NT, CAP, false, BIG>(p, acc, ind, dat, Y, cache, n, lane, h, c);
-            symv_collect<NT>(smem, p, Ap, w, seq, c);
+            unscale = symv_publish<NT>(smem, p, pbound, w, ++seq, lane, h, c) * gsc[1];
+            sparse_pass<NT, CAP, false, BIG, RS>(p, acc, ind, dat, Y, cache, n, lane, h, c, R);
+            symv_collect<NT>(smem, p, Ap, unscale, w, seq, c);
             part = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -750,6 +842,7 @@ __global__ __launch_bounds__(1024) void als_short_mfma_kernel(
             const float beta = rsnew / rsold;
 #pragma unroll
             for (int t = 0; t < NT; ++t) p[t] = fmaf(beta, p[t], rr[t]);
+            pbound = (sqrtf(rsnew) + fabsf(beta) * pbound) * 1.0001f;
             rsold = rsnew;
         }
         if (h == 0) store_n<NT>(xg, x);
@@ -854,8 +947,8 @@ int als_short_cache_rows(int nt) {
         case 2: return ShortLds<2>::CAP;
         case 4: return ShortLds<4>::CAP;
 #else
-        case 2: return MfmaShort<2>::CAP;
-        case 4: return MfmaShort<4>::CAP;
+        case 2: return MfmaShort<2>::CAP + MfmaShort<2>::RS * STEP;
+        case 4: return MfmaShort<4>::CAP + MfmaShort<4>::RS * STEP;
 #endif
         case 3: return ShortLds<3>::CAP;
         case 5: return ShortLds<5>::CAP;
