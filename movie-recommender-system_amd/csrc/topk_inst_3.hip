@@ -15,10 +15,4 @@ extern "C" int mirec_topk_debug_read(unsigned long long* out, int reset) {
     }
     return 0;
 }
-extern "C" int mirec_topk_debug_trace(unsigned* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mirec::mirec_topk_trace), sizeof(unsigned) * 20 * 1024) == hipSuccess ? 0 : -3;
-}
-extern "C" int mirec_topk_debug_mode(int mode) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(mirec::mirec_topk_dbg_mode), &mode, sizeof(int)) == hipSuccess ? 0 : -3;
-}
 #endif

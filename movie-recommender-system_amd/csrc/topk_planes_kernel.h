@@ -12,47 +12,63 @@
 // of the scores around rank k.  The selection is therefore run with a margin
 // and the survivors are scored again, exactly:
 //
-//   * tau~ = k-th best s~ seen by a query so far.  At most k - 1 items have
-//     s > s_(k), so tau~ <= s_(k) + eps at all times, while every member of the
-//     exact top k has s~ >= s_(k) - eps: a buffer that holds every item with
-//     s~ > tau~ - 2 eps holds the exact top k, ties at the boundary included.
+//   * tau~ = a lower bound of the k-th best s~ seen by a query so far.  At most
+//     k - 1 items have s > s_(k), so tau~ <= s_(k) + eps at all times, while every
+//     member of the exact top k has s~ >= s_(k) - eps: a buffer that holds every
+//     item with s~ > tau~ - 2 eps holds the exact top k, ties at the boundary
+//     included.
 //   * At the end the buffered candidates (k plus the few inside the margin) are
 //     scored with the fp32 fma chain in ascending k -- bit for bit what the fp32
 //     MFMA kernel computes -- and the k best under (score desc, item asc) are
 //     written.
 //   * A query whose margin set outgrows its buffer (heavy ties), whose margin is
-//     not finite, or whose filter leaves fewer than k items is not answered here:
-//     it is appended to a device-side list and the fp32 kernel answers it in list
-//     mode afterwards.  Liked items are simply never buffered.
+//     zero or not finite (a zero query row, all-zero items, overflow), or whose
+//     filter leaves fewer than k items is not answered here: it is appended to a
+//     device-side list and the fp32 kernel answers it in list mode afterwards.
+//     Liked items are simply never buffered.
 //
-// A workgroup owns 32*WM query rows.  Its WM "matrix" waves keep 32 queries each
-// as split MFMA A operands in registers, sweep the items in tiles of 32 and do
-// nothing but plane staging (global -> registers -> LDS, double buffered),
-// operand reads, 3*F/16 MFMAs and four 16-byte stores of the score tile per item
-// tile.  Two "selector" waves per matrix wave consume the score tile of the
-// previous item tile and own all selection state: thresholds in registers, fill
-// counts as packed scalars, the candidates of a query row straight from the
-// compare's lane mask (which also assigns their slots -- no atomics), liked
-// items from a per-query cursor fed by a small LDS ring, buffers compacted by a
-// digit-serial k-th-best search (no sort) when a tile's candidates would not
-// fit and on a tile schedule that all selectors share.  One workgroup barrier
-// per item tile separates producers and consumers of the double-buffered images.
+// Every wavefront does the same work.  A workgroup of NW wavefronts owns 32*NW
+// queries, 32 per wavefront, which the wavefront keeps as split MFMA B operands
+// in registers; the item tiles (32 items, both planes) pass through a ring of
+// images in LDS and are the A operands.  The 32 x 32 result then has one QUERY
+// per lane column: lanes c and c + 32 hold the scores of query c for 16 items
+// each.  Everything the selection needs is therefore per lane -- the entry
+// threshold is one register, "does this tile hold a candidate" is a register
+// maximum and one compare, and the candidates of different queries are appended
+// side by side under the execution mask (one LDS atomic reserves the slot) -- so
+// the scores never leave the registers and no wavefront waits for another's
+// selection.  When an append finds a buffer full the wavefront compacts the
+// buffers of all its queries at once, again one query per lane pair: a bisection
+// on the value range finds a lower bound of the k-th best entry, the entries
+// above it (minus the margin) are kept and the threshold is raised.
+//
+// No workgroup barrier inside the sweep: every wavefront publishes its progress
+// in LDS (images stored, images read) and waits only for what it is about to
+// touch, and the ring lets a wavefront that compacts fall an image behind
+// without stopping the rest.
+//
+// Measured (1 M queries x 27 k items, F = 128, k = 20, liked-item filter on, one MI355X): 29.5 ms, against 33.1 ms
+// for the previous design (four matrix wavefronts handing score tiles through LDS to eight selector wavefronts,
+// item-per-lane).  Counters: 385 instructions per wavefront and tile (180 vector, 24 matrix, 137 scalar, 39 LDS),
+// the matrix pipe 28 % busy -- the sweep is bound by instruction issue of the selection, not by the products.
+// Probe builds (-DMIREC_PROBE_TK_NOSCAN, _NOWALK, _NOMFMA, _NOSYNC; wrong results, timing only) leave out
+// one part each: without the matrix instructions 13.7 ms, without selection and walk 17.4 ms.
 #pragma once
 #include "topk_kernel.h"
 #include "topk_workspace.h"
 
 namespace mirec {
 
-// Optional phase timing (-DMIREC_DEBUG_TIMING): cycle counts of one matrix wave and one selector wave of every
-// workgroup, summed into a per-translation-unit counter array; the F = 128 unit exports
+// Optional phase timing (-DMIREC_DEBUG_TIMING): cycle counts of the sections of the sweep, of the first wavefront
+// of every workgroup, summed into a per-translation-unit counter array; the F = 128 unit exports
 // mirec_topk_debug_read (tools/probes/topk_phase_timing.py).
 #ifdef MIREC_DEBUG_TIMING
 static __device__ unsigned long long mirec_topk_dbg[16];
-static __device__ int mirec_topk_dbg_mode;  // bits 8 and up: the workgroup whose tiles are traced
-static __device__ unsigned mirec_topk_trace[20][1024];  // per tile, of workgroup mirec_topk_dbg_mode >> 8
 #define TKS_T() __builtin_readcyclecounter()
+#define TKS_ADD(i, v) dbg[i] += (v)
 #else
 #define TKS_T() 0ull
+#define TKS_ADD(i, v)
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 tk_bf16x8;
@@ -143,378 +159,216 @@ __global__ __launch_bounds__(32 * (F / 8)) void topk_split_items_kernel(const fl
     }
 }
 
-// Sort one query's buffer (n <= CAP entries, wave-uniform n) under (score desc, item asc) and keep the sorted
-// prefix of the entries that beat  (k-th best score) - marg,  at most `limit` of them.  Returns the number
-// kept; thr_out = the new entry threshold, over = the margin set did not fit.
-template <int CAP>
-__device__ __forceinline__ int compact_margin(float* ss, int* ii, int n_in, int k, int lane, float marg, int limit,
-                                              float& thr_out, bool& over) {
-    constexpr int E = (CAP + 63) / 64;
-    const int n = __builtin_amdgcn_readfirstlane(n_in);
-    __builtin_amdgcn_wave_barrier();
-    float ms[E];
-    int mi[E];
-    int rank[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int idx = lane + 64 * e;
-        ms[e] = idx < n ? ss[idx] : -INFINITY;
-        mi[e] = idx < n ? ii[idx] : 0x7fffffff;
-        rank[e] = 0;
-    }
-    for (int j = 0; j < n; ++j) {
-        const float sj = ss[j];
-        const int ij = ii[j];
-#pragma unroll
-        for (int e = 0; e < E; ++e) rank[e] += better(sj, ij, ms[e], mi[e]) ? 1 : 0;
-    }
-    float tau = -INFINITY;
-    if (n >= k) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const unsigned long long mm = __ballot(lane + 64 * e < n && rank[e] == k - 1);
-            if (mm != 0ull)
-                tau = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ms[e]), __builtin_ctzll(mm)));
-        }
-    }
-    const float thr = tau - marg;
-    int keepn = 0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) keepn += __builtin_popcountll(__ballot(lane + 64 * e < n && ms[e] > thr));
-    const int nk = n < k ? n : k;
-    keepn = keepn > nk ? keepn : nk;  // a zero margin (zero query row: every score is exactly 0) keeps the k best
-    over = keepn > limit;
-    const int keep = keepn < limit ? keepn : limit;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int idx = lane + 64 * e;
-        if (idx < n && rank[e] < keep) {
-            ss[rank[e]] = ms[e];
-            ii[rank[e]] = mi[e];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    thr_out = thr;
-    return keep;
+// Register i of a lane in half h of a 32 x 32 MFMA result is row tk_rowpos(i) + 4 * h.
+__device__ __forceinline__ constexpr int tk_rowpos(int i) { return (i & 3) + 8 * (i >> 2); }
+
+// The values that the two lanes of a pair (c, c + 32) hold: .x of the lane in the first half-wave, .y of the other
+// (the same in both lanes of the pair; a vector-ALU lane swap, not an LDS access).
+struct tk_pair_u32 {
+    uint32_t x, y;
+};
+__device__ __forceinline__ tk_pair_u32 tk_pair(uint32_t v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return tk_pair_u32{r[0], r[1]};
+}
+__device__ __forceinline__ float tk_pair_min(float v) {
+    const tk_pair_u32 p = tk_pair(__float_as_uint(v));
+    return fminf(__uint_as_float(p.x), __uint_as_float(p.y));
+}
+__device__ __forceinline__ float tk_pair_max(float v) {
+    const tk_pair_u32 p = tk_pair(__float_as_uint(v));
+    return fmaxf(__uint_as_float(p.x), __uint_as_float(p.y));
+}
+__device__ __forceinline__ int tk_pair_sum(int v) {
+    const tk_pair_u32 p = tk_pair((uint32_t)v);
+    return (int)(p.x + p.y);
 }
 
-// Sweep-time compaction of one query's buffer (n <= CAP <= 64 entries, one per lane, n >= k): find the k-th
-// best score tau by a digit-serial search on an order-preserving integer image of the scores (three compares
-// and population counts per two bits, no sort), then keep -- in place, in buffer order, which is ascending item
-// order and stays so -- the entries that beat tau - marg; among entries equal to tau the earliest ones
-// complete the k when the margin does not cover them (zero margin).  At most `limit` entries are kept.
-// Returns the number kept; thr_out = the new entry threshold, over = the margin set did not fit.
-template <int CAP>
-__device__ __forceinline__ int compact_select(float* ss, int* ii, int n_in, int k, int lane, float marg, int limit,
-                                              float& thr_out, bool& over) {
-    static_assert(CAP <= 64, "one entry per lane");
-    const int n = __builtin_amdgcn_readfirstlane(n_in);
-    __builtin_amdgcn_wave_barrier();
-    const bool valid = lane < n;
-    const float sv = valid ? ss[lane] : -INFINITY;
-    const int iv = valid ? ii[lane] : 0;
-    const uint32_t bits = __float_as_uint(sv);
-    const uint32_t key = valid ? (bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u)) : 0u;
-    // Two bits per step: the three trial values are independent compares.  The search stops at bit 12: the
-    // result is then a lower bound of the k-th best score, at most 2^-11 below it in relative terms, which is
-    // all a threshold needs (the entries between the two are simply kept).
-    auto count_ge = [&](uint32_t trial) __attribute__((always_inline)) {
-        return __builtin_popcountll(__builtin_amdgcn_uicmp(key, trial, 35 /* unsigned >= */));
-    };
-    uint32_t prefix = 0u;
-#pragma unroll
-    for (int b = 30; b >= 12; b -= 2) {
-        const int c1 = count_ge(prefix | (1u << b));
-        const int c2 = count_ge(prefix | (2u << b));
-        const int c3 = count_ge(prefix | (3u << b));
-        const uint32_t add = c3 >= k ? 3u : (c2 >= k ? 2u : (c1 >= k ? 1u : 0u));
-        prefix |= add << b;
-    }
-    const uint32_t tb = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
-    const float tau = __uint_as_float(tb);
-    const float thr = tau - marg;
-    const unsigned long long gtm = __ballot(valid && sv > tau);
-    const unsigned long long eqm = __ballot(valid && sv == tau);
-    const int need = k - __builtin_popcountll(gtm);
-    const int eq_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(eqm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eqm, 0u));
-    const bool keep = valid && (sv > thr || (sv == tau && eq_rank < need));
-    const unsigned long long km = __ballot(keep);
-    const int keepn = __builtin_popcountll(km);
-    over = keepn > limit;
-    const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-    __builtin_amdgcn_wave_barrier();
-    if (keep && pos < limit) {
-        ss[pos] = sv;
-        ii[pos] = iv;
-    }
-    __builtin_amdgcn_wave_barrier();
-    thr_out = thr;
-    return keepn < limit ? keepn : limit;
+__device__ __forceinline__ int tk_load_acquire(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void tk_store_release(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Wait until each of the NW progress words at p (one per wavefront of the workgroup, in LDS, only growing) has
+// reached `need`.  Lane l looks at the word of wavefront l.
+template <int NW>
+__device__ __forceinline__ void tk_wait_all(const int* p, int need, int lane) {
+    while (__ballot(lane < NW && tk_load_acquire(p + (lane < NW ? lane : 0)) < need) != 0ull) __builtin_amdgcn_s_sleep(1);
 }
 
-// Keep the best min(n, k) entries of one query's buffer (n <= CAP, wave-uniform), sorted, at the front;
-// returns the new fill count.
-template <int CAP>
-__device__ __forceinline__ int compact_sorted(float* ss, int* ii, int n_in, int k, int lane) {
-    constexpr int E = (CAP + 63) / 64;
-    const int n = __builtin_amdgcn_readfirstlane(n_in);
-    __builtin_amdgcn_wave_barrier();
-    float ms[E];
-    int mi[E];
-    int rank[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int idx = lane + 64 * e;
-        ms[e] = idx < n ? ss[idx] : -INFINITY;
-        mi[e] = idx < n ? ii[idx] : 0x7fffffff;
-        rank[e] = 0;
-    }
-    for (int j = 0; j < n; ++j) {
-        const float sj = ss[j];
-        const int ij = ii[j];
-#pragma unroll
-        for (int e = 0; e < E; ++e) rank[e] += better(sj, ij, ms[e], mi[e]) ? 1 : 0;
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int idx = lane + 64 * e;
-        if (idx < n && rank[e] < k) {
-            ss[rank[e]] = ms[e];
-            ii[rank[e]] = mi[e];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return n < k ? n : k;
-}
-
-constexpr int TOPK_PLANES_SEL = 2;      // selector waves per matrix wave
-constexpr int TOPK_EARLY_COMPACT = 8;   // entries beyond k that make a buffer worth compacting on the schedule
-
-template <int F, int WM, int CAP>
+template <int F, int NW, int CAP, int PD>
 struct TopkPlanesLds {
-    static constexpr int SEL = TOPK_PLANES_SEL;
-    static constexpr int NW = WM * (1 + SEL);
+    static constexpr int NQ = 32 * NW;  // queries of a workgroup
     // One plane of an item tile: 32 rows of F bf16, padded by 16 bytes: the row stride in dwords is an odd
     // multiple of four, which puts the 16 rows of every ds_read_b128 group on disjoint banks.
     static constexpr int ROWB = 2 * F + 16;
     static constexpr int PLANEB = TOPK_BI * ROWB;
     static constexpr int TILEB = TOPK_NPLANES * PLANEB;
-    static constexpr int ST = 64 * 16;  // floats of one score tile: [i >> 2][lane][i & 3]
-    // per matrix wave: scores, ids, liked bits, count / threshold / margin words, liked-item rings
     static constexpr int RING = 8;  // liked-item look-ahead per query (a power of two, at least 8)
-    static constexpr int PER_M = 32 * CAP * 2 + 32 * 4 + 32 * RING;
-    static constexpr size_t BYTES = (size_t)2 * TILEB + (size_t)(2 * WM * ST + WM * PER_M) * 4;
+    // in floats: the item images; candidate scores and ids, entry-major ([entry][query]: the lanes of a
+    // half-wave, one query each, touch 32 consecutive words); fill counts; liked-item rings; the two counters
+    static constexpr int SEL_S = PD * TILEB / 4;
+    static constexpr int SEL_I = SEL_S + CAP * NQ;
+    static constexpr int CNT = SEL_I + CAP * NQ;
+    static constexpr int RINGS = CNT + NQ;
+    static constexpr int SYNC = RINGS + NQ * RING;
+    static constexpr int SYNC_WORDS = 32;  // per wavefront: item images stored, item images read
+    static_assert(NW <= 16, "progress words");
+    static constexpr size_t BYTES = (size_t)(SYNC + SYNC_WORDS) * 4;
+    static_assert(PD >= 3, "three item images are staged ahead of the sweep");
+    static constexpr int LIMIT = CAP - 16;  // entries a compaction may leave (at least k)
+    static_assert(CAP % 2 == 0 && LIMIT >= TOPK_PLANE_KMAX && LIMIT <= 32, "buffer size");
 };
 
-template <int F, int WM, int CAP>
-__global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_kernel(
+// Compaction of the buffers of all 32 queries of a wavefront at once.  Lane pair (c, c + 32) owns query slot q;
+// the lane in half h holds the entries 2j + h in registers.  For a query with at least k entries a bisection
+// on [min, max] finds lo with  #(entries >= lo) >= k  (so lo <= the k-th best entry), the smallest entry >= lo
+// takes its place (same count, tighter), the entry threshold becomes max(thr, lo - marg) and the entries above
+// it move to the front of the buffer.  Returns the number kept; over = more than LIMIT.
+template <int CAP, int NQ, int LIMIT>
+__device__ __forceinline__ int tk_compact_all(float* sel_s, int* sel_i, int* cnt, int q, int h, int k, float marg,
+                                              float& thr, bool& over) {
+    constexpr int NE = CAP / 2;
+    constexpr int STEPS = 9;
+    __builtin_amdgcn_wave_barrier();
+    int n = cnt[q];
+    n = n < CAP ? n : CAP;  // appends that found the buffer full have counted past it
+    float v[NE];
+    int id[NE];
+    float lo = INFINITY, hi = -INFINITY;
+    const float* my_s = sel_s + (h * NQ + q);  // entry 2j + h of the query: a constant offset from here
+    const int* my_i = sel_i + (h * NQ + q);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = 2 * j + h;
+        const float sv = my_s[2 * j * NQ];
+        id[j] = my_i[2 * j * NQ];
+        v[j] = e < n ? sv : -INFINITY;
+        lo = e < n ? fminf(lo, sv) : lo;
+        hi = fmaxf(hi, v[j]);
+    }
+    lo = tk_pair_min(lo);
+    hi = tk_pair_max(hi);
+    if (n >= k) {
+#pragma unroll 1
+        for (int step = 0; step < STEPS; ++step) {
+            const float mid = 0.5f * lo + 0.5f * hi;
+            int cge = 0;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) cge += v[j] >= mid ? 1 : 0;
+            cge = tk_pair_sum(cge);
+            lo = cge >= k ? mid : lo;
+            hi = cge >= k ? hi : mid;
+        }
+        float t = INFINITY;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) t = v[j] >= lo ? fminf(t, v[j]) : t;
+        lo = tk_pair_min(t);
+        thr = fmaxf(thr, lo - marg);
+    }
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) mine += v[j] > thr ? 1 : 0;
+    const tk_pair_u32 cn = tk_pair((uint32_t)mine);
+    const int total = (int)(cn.x + cn.y);
+    over = total > LIMIT;
+    int pos = h ? (int)cn.x : 0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        if (v[j] > thr) {
+            sel_s[pos * NQ + q] = v[j];
+            sel_i[pos * NQ + q] = id[j];
+            ++pos;
+        }
+    }
+    if (h == 0) cnt[q] = total;
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
+
+template <int F, int NW, int CAP, int PD>
+__global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const float* __restrict__ Q, int64_t nq, const float* __restrict__ Y, int64_t ni,
     const uint32_t* __restrict__ planes, const uint32_t* __restrict__ ymax_bits,
     const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices, int k,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int32_t* __restrict__ qlist,
     int32_t* __restrict__ qcount) {
-    using L = TopkPlanesLds<F, WM, CAP>;
+    using L = TopkPlanesLds<F, NW, CAP, PD>;
     constexpr int KS = F / 16;  // MFMA k-steps
     constexpr int F8 = F / 8;   // 16-byte chunks per plane row
     constexpr int BI = TOPK_BI;
-    constexpr int SEL = L::SEL;
-    constexpr int NROW = 16 / SEL;  // score rows (of each half-wave) per selector
+    constexpr int NQ = L::NQ;
+    constexpr int RING = L::RING;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ybuf = reinterpret_cast<char*>(smem);
-    float* sbuf = smem + 2 * L::TILEB / 4;
+    float* sel_s = smem + L::SEL_S;
+    int* sel_i = reinterpret_cast<int*>(smem + L::SEL_I);
+    int* cnt = reinterpret_cast<int*>(smem + L::CNT);
+    int* rings = reinterpret_cast<int*>(smem + L::RINGS);
+    int* sync = reinterpret_cast<int*>(smem + L::SYNC);
+    int* staged = sync;        // [w]: wavefront w has stored its share of the images of the tiles below this number
+    int* read_done = sync + 16;  // [w]: wavefront w has finished the matrix phase of the tiles below this number
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int h = lane >> 5;
     const int c = lane & 31;
     const int ntile = (int)((ni + BI - 1) / BI);
+    const int q = w * 32 + c;  // this lane pair's query slot
+    const int64_t ug = (int64_t)blockIdx.x * NQ + q;
+    const bool uv = ug < nq;
 
-    if (w < WM) {
-        // ------------------------------------------------------------ matrix wave
-        const int64_t u0 = (int64_t)blockIdx.x * (32 * WM) + w * 32;
-        // A operands: query row u0 + c, factors 16*ks + 8*h .. + 7, as two bf16 planes
-        tk_u32x4 qh[KS], qm[KS];
-        {
-            const int64_t u = u0 + c;
-            const bool uv = u < nq;
-            const float* qr = Q + (uv ? u : 0) * F + 8 * h;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                f32x4 a = *reinterpret_cast<const f32x4*>(qr + 16 * s);
-                f32x4 b = *reinterpret_cast<const f32x4*>(qr + 16 * s + 4);
-                if (!uv) {
-                    a = f32x4{0.f, 0.f, 0.f, 0.f};
-                    b = a;
-                }
-                tk_split8(a, b, qh[s], qm[s]);
-            }
-        }
-        // Plane staging by the matrix waves (the selectors' time per tile varies, the matrix waves' does not):
-        // tile t + 2 is in registers during the MFMAs of tile t and goes to LDS at the start of tile t + 1.
-        constexpr int NTS = 64 * WM;
-        constexpr int TILE_CH = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile
-        constexpr int NV = (TILE_CH + NTS - 1) / NTS;
-        tk_u32x4 pre[NV];
-        // Unconditional loads (a branch around a load makes the compiler wait for it on the spot): threads past
-        // the tile repeat its last chunk.
-        auto load_y = [&](int t) __attribute__((always_inline)) {
-            const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_CH;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                int e = tid + v * NTS;
-                e = e < TILE_CH ? e : TILE_CH - 1;
-                pre[v] = src[e];
-            }
-        };
-        auto store_y = [&](char* ytile) __attribute__((always_inline)) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                int e = tid + v * NTS;
-                e = e < TILE_CH ? e : TILE_CH - 1;  // duplicates write the same values
-                const int row = e / F8;             // plane * 32 + item
-                const int kc = e % F8;
-                *reinterpret_cast<tk_u32x4*>(ytile + row * L::ROWB + 16 * kc) = pre[v];
-            }
-        };
-        if (ntile > 0) {
-            load_y(0);
-            store_y(ybuf);
-        }
-        load_y(ntile > 1 ? 1 : 0);
-        __syncthreads();  // tile 0 is staged
-        unsigned long long dm = 0, db = 0;
-        for (int t = 0; t < ntile; ++t) {
-            const unsigned long long t0 = TKS_T();
-            // rows past the last tile repeat it: the loads stay unconditional, their stores land in the idle image
-            store_y(ybuf + ((t + 1) & 1) * L::TILEB);
-            load_y(t + 2 < ntile ? t + 2 : ntile - 1);
-            const char* yb = ybuf + (t & 1) * L::TILEB + c * L::ROWB + 16 * h;
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc0[i] = 0.f;
-                acc1[i] = 0.f;
-            }
-            // B operands are fetched one k-step ahead of the MFMAs that consume them
-            tk_u32x4 bq[2][TOPK_NPLANES];
-            auto fetch = [&](tk_u32x4 (&dst)[TOPK_NPLANES], int s) __attribute__((always_inline)) {
-#pragma unroll
-                for (int p = 0; p < TOPK_NPLANES; ++p) dst[p] = *reinterpret_cast<const tk_u32x4*>(yb + p * L::PLANEB + 32 * s);
-            };
-            fetch(bq[0], 0);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (s + 1 < KS) fetch(bq[(s + 1) & 1], s + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const tk_u32x4(&b)[TOPK_NPLANES] = bq[s & 1];
-                // mid * mid is below 2^-18 of |q_k y_k| and left to the margin
-                if (s & 1) {
-                    acc1 = tk_mma(qh[s], b[0], acc1);  // hi hi
-                    acc0 = tk_mma(qh[s], b[1], acc0);  // hi mid
-                    acc1 = tk_mma(qm[s], b[0], acc1);  // mid hi
-                } else {
-                    acc0 = tk_mma(qh[s], b[0], acc0);  // hi hi
-                    acc1 = tk_mma(qh[s], b[1], acc1);  // hi mid
-                    acc0 = tk_mma(qm[s], b[0], acc0);  // mid hi
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float* st = sbuf + ((t & 1) * WM + w) * L::ST + lane * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(st + q * 256) =
-                    f32x4{acc0[4 * q] + acc1[4 * q], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2],
-                          acc0[4 * q + 3] + acc1[4 * q + 3]};
-            const unsigned long long t1 = TKS_T();
-            __syncthreads();  // score tile t is complete; plane tile t + 1 is staged
-            dm += t1 - t0;
-            db += TKS_T() - t1;
-#ifdef MIREC_DEBUG_TIMING
-            if (lane == 0 && (int)blockIdx.x == (mirec_topk_dbg_mode >> 8) && t < 1024) {
-                mirec_topk_trace[16 + w][t] = (unsigned)(t1 - t0);
-                if (w == 0) mirec_topk_trace[8][t] = (unsigned)(TKS_T() - t0);
-            }
-#endif
-        }
-#ifdef MIREC_DEBUG_TIMING
-        if (tid == 0) {
-            atomicAdd(&mirec_topk_dbg[0], dm);
-            atomicAdd(&mirec_topk_dbg[1], db);
-            atomicAdd(&mirec_topk_dbg[2], (unsigned long long)ntile);
-        }
-#endif
-        return;
-    }
+    if (tid < L::SYNC_WORDS) sync[tid] = tid < 16 ? 3 : 0;  // tiles 0 to 2 are staged before the sweep
+    if (h == 0) cnt[q] = 0;
 
-    // ---------------------------------------------------------------- selector wave
-    const int sw = w - WM;             // selector index in the workgroup
-    const int m = sw / SEL;            // the matrix wave it serves
-    const int r0 = (sw % SEL) * NROW;  // its score rows: i in [r0, r0 + NROW)
-    const int64_t u0 = (int64_t)blockIdx.x * (32 * WM) + m * 32;
-    float* sel_s = smem + 2 * L::TILEB / 4 + 2 * WM * L::ST + m * L::PER_M;
-    int* sel_i = reinterpret_cast<int*>(sel_s + 32 * CAP);
-    unsigned* lmask = reinterpret_cast<unsigned*>(sel_i + 32 * CAP);  // [32]: liked bits of the current item tile
-    int* st_cnt = reinterpret_cast<int*>(lmask + 32);                 // [32]: fill counts
-    float* st_thr = reinterpret_cast<float*>(st_cnt + 32);            // [32]: entry thresholds
-    float* st_marg = st_thr + 32;                                     // [32]: margins
-    int* ring = reinterpret_cast<int*>(st_marg + 32);                 // [32][RING]: upcoming liked items per query
-    constexpr int RING = L::RING;
-    auto row_of = [&](int i, int hh) __attribute__((always_inline)) { return (i & 3) + 8 * (i >> 2) + 4 * hh; };
-
-    // Score row i of this lane belongs to query row_of(i, h).  The entry threshold (k-th best score so far minus
-    // the margin) of a row is identical in the 32 lanes of a half-wave and mirrored in registers for the
-    // per-tile compare; rows past the last query get +inf: nothing ever beats it.  Counts, thresholds and
-    // margins live in LDS: they are touched only for rows that have a candidate.
-    float thr_r[NROW];
+    // B operands: query row ug, factors 16*s + 8*h .. + 7, as two bf16 planes; and the margin of the query
+    tk_u32x4 qh[KS], qm[KS];
+    float marg;
     {
-        const float ymax = __uint_as_float(*ymax_bits);
+        const float* qr = Q + (uv ? ug : 0) * F + 8 * h;
+        float n2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NROW; ++j) {
-            const int ur = row_of(r0 + j, h);
-            const int64_t ug = u0 + ur;
-            const bool uv = ug < nq;
-            float s = 0.f;
-#pragma unroll
-            for (int e = c; e < F; e += 32) {
-                const float v = Q[(uv ? ug : 0) * F + e];
-                s += v * v;
+        for (int s = 0; s < KS; ++s) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(qr + 16 * s);
+            f32x4 b = *reinterpret_cast<const f32x4*>(qr + 16 * s + 4);
+            if (!uv) {
+                a = f32x4{0.f, 0.f, 0.f, 0.f};
+                b = a;
             }
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            // zero only for a zero query row or all-zero items (all scores exactly 0 on both pipes); otherwise
-            // at least the absolute error that products in the denormal range can add
-            const float qn = sqrtf(s);
-            const float marg = (qn > 0.f && ymax > 0.f)
-                                   ? 2.f * topk_eps_coef<F>() * qn * ymax + (float)(8 * F + 64) * 2.4e-38f
-                                   : qn * ymax;
-            thr_r[j] = uv ? -INFINITY : INFINITY;
-            if (c == 0) {
-                st_marg[ur] = marg;
-                st_thr[ur] = thr_r[j];
-                st_cnt[ur] = 0;
-            }
+            n2 += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] +
+                  b[3] * b[3];
+            tk_split8(a, b, qh[s], qm[s]);
         }
+        const tk_pair_u32 pn = tk_pair(__float_as_uint(n2));
+        const float qn = sqrtf(__uint_as_float(pn.x) + __uint_as_float(pn.y));
+        const float ymax = __uint_as_float(*ymax_bits);
+        // the second term: at least the absolute error that products in the denormal range can add
+        marg = (qn > 0.f && ymax > 0.f) ? 2.f * topk_eps_coef<F>() * qn * ymax + (float)(8 * F + 64) * 2.4e-38f
+                                        : qn * ymax;
     }
-    unsigned ovf = 0u;  // wave-uniform, bit ur: the margin set of that query outgrew its buffer
+    // A zero margin means all scores are exactly zero on both pipes and only the order of the ids decides; a
+    // margin that is not finite covers nothing.  Both go to the fp32 kernel.
+    const bool unfit = !(marg > 0.f && marg < INFINITY);
+    // Entry threshold of the query: a score enters the buffer only if it beats it.  +inf: nothing ever does.
+    float thr = (uv && !unfit) ? -INFINITY : INFINITY;
+    bool ovf = false;  // the margin set outgrew the buffer
 
-    // Liked-item filter: lane l < 2*NROW walks the (ascending) mask row of one of this selector's queries.  The
-    // row's upcoming entries sit in a small LDS ring, [cur, tail) of the row, refilled four at a time by loads
-    // that are issued with the plane staging and committed a tile later -- the walk itself never waits for
-    // memory unless one query has more liked items in a tile than the ring delivers.
-    const int my_ur = row_of(r0 + (lane % NROW), (lane / NROW) & 1);
-    int* my_ring = ring + my_ur * RING;
+    // Liked-item filter: the lane of the first half-wave walks the (ascending) mask row of its query.  The row's
+    // upcoming entries sit in a small LDS ring, [cur, tail) of the row, refilled four at a time by loads that are
+    // issued with the plane staging and committed a tile later -- the walk itself never waits for memory unless one
+    // query has more liked items in a tile than the ring delivers.
+    int* my_ring = rings + q * RING;
     const int32_t* mrow = mask_indices;
     int cur = 0, tail = 0, mlen = 0, pend_base = -1;
     int nxt = 0x7fffffff, nxt2 = 0x7fffffff;  // the row's entries cur and cur + 1 (0x7fffffff: none, or not read yet)
     int rf[4] = {0, 0, 0, 0};
-    const bool walker = mask_indptr != nullptr && lane < 2 * NROW && u0 + my_ur < nq;
+    const bool walker = mask_indptr != nullptr && h == 0 && uv;
     if (walker) {
-        const int64_t b = mask_indptr[u0 + my_ur];
+        const int64_t b = mask_indptr[ug];
         mrow = mask_indices + b;
-        mlen = (int)(mask_indptr[u0 + my_ur + 1] - b);
+        mlen = (int)(mask_indptr[ug + 1] - b);
         tail = mlen < RING ? mlen : RING;
         for (int e = 0; e < tail; ++e) my_ring[e] = mrow[e];
         // read back from the ring, not from memory: a register that may still be waiting for a memory load
@@ -523,7 +377,6 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
         if (mlen > 0) nxt = my_ring[0];
         if (mlen > 1) nxt2 = my_ring[1];
     }
-    if (lane < 2 * NROW) lmask[my_ur] = 0u;
     auto mask_refill_issue = [&]() __attribute__((always_inline)) {
         // room for four more and something left to fetch; loads are unconditional (clamped) inside the branch
         if (walker && tail < mlen && tail - cur <= RING - 4) {
@@ -545,75 +398,25 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
             pend_base = -1;
         }
     };
-
-    const int stid = tid - 64 * WM;
-
-    // Fill counts: wave-uniform, one byte per row, packed per half-wave (a count never exceeds CAP <= 255)
-    static_assert(CAP <= 255, "fill counts are kept in bytes");
-    unsigned cnt_p[2][NROW / 4];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int q = 0; q < NROW / 4; ++q) cnt_p[hh][q] = 0u;
-    auto cnt_get = [&](int hh, int j) __attribute__((always_inline)) { return (int)((cnt_p[hh][j >> 2] >> (8 * (j & 3))) & 0xffu); };
-    auto cnt_add = [&](int hh, int j, int d) __attribute__((always_inline)) { cnt_p[hh][j >> 2] += (unsigned)d << (8 * (j & 3)); };
-    // the same with a (wave-uniform) run-time row
-    auto cnt_get_dyn = [&](int hh, int j) __attribute__((always_inline)) {
-        unsigned wv = 0u;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int q = 0; q < NROW / 4; ++q) wv = (a == hh && q == (j >> 2)) ? cnt_p[a][q] : wv;
-        return (int)((wv >> (8 * (j & 3))) & 0xffu);
-    };
-    auto cnt_set_dyn = [&](int hh, int j, int v) __attribute__((always_inline)) {
-        const unsigned sh = 8u * (unsigned)(j & 3);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int q = 0; q < NROW / 4; ++q)
-                cnt_p[a][q] = (a == hh && q == (j >> 2)) ? ((cnt_p[a][q] & ~(0xffu << sh)) | ((unsigned)v << sh)) : cnt_p[a][q];
-    };
-    int sched_next = 5;  // next item tile with a scheduled compaction: 5, 13, 33, 83, 208, 521, ...
-    auto counts_to_lds = [&]() __attribute__((always_inline)) {
-        if (lane == 0) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int j = 0; j < NROW; ++j) st_cnt[row_of(r0 + j, hh)] = cnt_get(hh, j);
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    unsigned long long dbg_a = 0, dbg_b = 0;
-    // Selection over the score tile of item tile tt
-    auto select_tile = [&](int tt) __attribute__((always_inline)) {
-        const int i0 = tt * BI;
-        const int item = i0 + c;
-        // the scores are requested first: their way from LDS overlaps the liked-item walk
-        const float* sb = sbuf + ((tt & 1) * WM + m) * L::ST + lane * 4;
-        f32x4 scv[NROW / 4];
-#pragma unroll
-        for (int q = 0; q < NROW / 4; ++q) scv[q] = *reinterpret_cast<const f32x4*>(sb + (r0 / 4 + q) * 256);
-        bool tile_liked = false;  // wave-uniform: some query of this selector has a liked item in the tile
-        unsigned mw = 0u;         // walker lane hh * NROW + j: liked bits of the tile for query row_of(r0 + j, hh)
-        if (mask_indptr != nullptr) {
-            if (lane < 2 * NROW) {
-                const int lim = i0 + BI;
-                bool dry = false;
-                // The common case -- at most one liked item of a query in a tile -- without a loop and without
-                // waiting for LDS: the entry after the one consumed is already in a register, the one after that is
-                // requested now and not looked at before the next tile.
-                bool more = false;
-                if (nxt < lim) {
-                    const int bit = nxt - i0;
-                    if (bit >= 0) mw |= 1u << bit;
-                    ++cur;
-                    nxt = nxt2;
-                    nxt2 = cur + 1 < tail ? my_ring[(cur + 1) & (RING - 1)] : 0x7fffffff;
-                    more = nxt < lim || (nxt == 0x7fffffff && cur < mlen);
-                }
-                if (__ballot(more) != 0ull) {
+    // Liked bits of the items [i0, i0 + 32) for this lane's query (walker lanes; bit b: item i0 + b).
+    auto walk_tile = [&](int i0) __attribute__((always_inline)) -> unsigned {
+        unsigned mw = 0u;
+        if (walker) {
+            const int lim = i0 + BI;
+            bool dry = false;
+            // The common case -- at most one liked item of a query in a tile -- without a loop and without
+            // waiting for LDS: the entry after the one consumed is already in a register, the one after that is
+            // requested now and not looked at before the next tile.
+            bool more = false;
+            if (nxt < lim) {
+                const int bit = nxt - i0;
+                if (bit >= 0) mw |= 1u << bit;
+                ++cur;
+                nxt = nxt2;
+                nxt2 = cur + 1 < tail ? my_ring[(cur + 1) & (RING - 1)] : 0x7fffffff;
+                more = nxt < lim || (nxt == 0x7fffffff && cur < mlen);
+            }
+            if (__ballot(more) != 0ull) {
                 if (more && nxt == 0x7fffffff && cur < mlen) {  // not read when it was prefetched: it may be there by now
                     if (cur < tail)
                         nxt = my_ring[cur & (RING - 1)];
@@ -656,215 +459,344 @@ __global__ __launch_bounds__(64 * WM * (1 + TOPK_PLANES_SEL)) void topk_planes_k
                         }
                     }
                 }
-                }
-            }
-            tile_liked = __ballot(mw != 0u) != 0ull;
-        }
-        float sc[NROW];
-#pragma unroll
-        for (int q = 0; q < NROW / 4; ++q) {
-            sc[4 * q] = scv[q][0];
-            sc[4 * q + 1] = scv[q][1];
-            sc[4 * q + 2] = scv[q][2];
-            sc[4 * q + 3] = scv[q][3];
-        }
-        dbg_a = TKS_T();
-        const unsigned long long okm = (tt == ntile - 1) ? __ballot(item < ni) : ~0ull;
-        // Row by row, the compare result is the lane mask of the candidates, which also gives every candidate its
-        // slot; counts are scalars.  A row whose buffer cannot take its candidates is deferred to the code below.
-        unsigned defer = 0u;
-#pragma unroll
-        for (int j = 0; j < NROW; ++j) {
-            unsigned long long mm = __ballot(sc[j] > thr_r[j]) & okm;
-            if (mm == 0ull) continue;
-            const int ur = row_of(r0 + j, h);
-            if (tile_liked) {
-                const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)mw, j);
-                const unsigned l1 = (unsigned)__builtin_amdgcn_readlane((int)mw, NROW + j);
-                mm &= ~((unsigned long long)l0 | ((unsigned long long)l1 << 32));
-                if (mm == 0ull) continue;
-            }
-            const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
-            const int pc0 = __builtin_popcount(m0), pc1 = __builtin_popcount(m1);
-            const int n0 = cnt_get(0, j), n1 = cnt_get(1, j);
-            if (n0 + pc0 > CAP || n1 + pc1 > CAP) {
-                defer |= 1u << j;
-                continue;
-            }
-            const int pos = h ? n1 + (int)__builtin_amdgcn_mbcnt_hi(m1, 0u) : n0 + (int)__builtin_amdgcn_mbcnt_lo(m0, 0u);
-            if ((mm >> lane) & 1ull) {
-                sel_s[ur * CAP + pos] = sc[j];
-                sel_i[ur * CAP + pos] = item;
-            }
-            cnt_add(0, j, pc0);
-            cnt_add(1, j, pc1);
-        }
-        // Buffers to compact now, bit 8*hh + j: those that cannot take this tile's candidates -- and, at tiles
-        // that every selector of the workgroup computes alike (a geometric schedule), all that have gathered
-        // enough new entries.  A compaction stalls every wave of the workgroup at the next barrier; on the
-        // schedule the selectors pay that together instead of one after the other, and the forced ones become rare.
-        dbg_b = TKS_T();
-        unsigned todo = 0u;
-        if (defer != 0u) {
-            if (tile_liked) {  // the deferred rows take the liked bits from LDS
-                if (lane < 2 * NROW) lmask[my_ur] = mw;
-                __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int j = 0; j < NROW; ++j) {
-                if (!((defer >> j) & 1u)) continue;
-                // recount this row's candidates per half (uniform): a half is compacted only if it would overflow
-                const unsigned long long mm = __ballot(sc[j] > thr_r[j] && item < ni &&
-                                                       !(tile_liked && ((lmask[row_of(r0 + j, h)] >> c) & 1u)));
-                if (cnt_get(0, j) + __builtin_popcount((unsigned)mm) > CAP) todo |= 1u << j;
-                if (cnt_get(1, j) + __builtin_popcount((unsigned)(mm >> 32)) > CAP) todo |= 1u << (8 + j);
             }
         }
-        if (tt == sched_next) {
-            sched_next = tt * 5 / 2 + 1;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int j = 0; j < NROW; ++j)
-                    if (cnt_get(hh, j) >= k + TOPK_EARLY_COMPACT) todo |= 1u << (8 * hh + j);
-        }
-        if (todo == 0u) return;
-        while (todo != 0u) {
-            const int b = __builtin_ctz(todo);
-            todo &= todo - 1u;
-            const int j = b & 7, hh = b >> 3;
-            const int urh = row_of(r0 + j, hh);
-            float tnew;
-            bool over;
-            const int newn = compact_select<CAP>(sel_s + urh * CAP, sel_i + urh * CAP, cnt_get_dyn(hh, j), k, lane,
-                                                 st_marg[urh], CAP - 32, tnew, over);
-            ovf |= over ? (1u << urh) : 0u;
-            cnt_set_dyn(hh, j, newn);
-            if (lane == 0) st_thr[urh] = tnew;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < NROW; ++j) thr_r[j] = st_thr[row_of(r0 + j, h)];
-        // the deferred rows' candidates, against the raised thresholds
-        while (defer != 0u) {
-            const int j = __builtin_ctz(defer);
-            defer &= defer - 1u;
-            const int ur = row_of(r0 + j, h);
-            const float s = sb[((r0 + j) >> 2) * 256 + ((r0 + j) & 3)];
-            bool cand = item < ni && s > st_thr[ur];
-            if (tile_liked) cand = cand && !((lmask[ur] >> c) & 1u);
-            const unsigned long long mm = __ballot(cand);
-            if (mm == 0ull) continue;
-            const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
-            const int n0 = cnt_get_dyn(0, j), n1 = cnt_get_dyn(1, j);
-            const int pos = h ? n1 + (int)__builtin_amdgcn_mbcnt_hi(m1, 0u) : n0 + (int)__builtin_amdgcn_mbcnt_lo(m0, 0u);
-            if (cand) {
-                sel_s[ur * CAP + pos] = s;
-                sel_i[ur * CAP + pos] = item;
-            }
-            cnt_set_dyn(0, j, n0 + __builtin_popcount(m0));
-            cnt_set_dyn(1, j, n1 + __builtin_popcount(m1));
-        }
+        return mw;
     };
 
-    __syncthreads();  // tile 0 is staged
-    unsigned long long ds = 0, dsel = 0, dbar = 0, dst = 0;
-    for (int t = 0; t < ntile; ++t) {
-        const unsigned long long t0 = TKS_T();
-        mask_refill_commit();
-        const unsigned long long t05 = TKS_T();
-        mask_refill_issue();
-        const unsigned long long t1 = TKS_T();
-        dst += t05 - t0;
-        if (t >= 1) select_tile(t - 1);
-        const unsigned long long t2 = TKS_T();
-        __syncthreads();  // score tile t is complete; plane tile t + 1 is staged
-        ds += t1 - t0;
-        dsel += t2 - t1;
-        dbar += TKS_T() - t2;
-#ifdef MIREC_DEBUG_TIMING
-        if (lane == 0 && (int)blockIdx.x == (mirec_topk_dbg_mode >> 8) && t < 1024) {
-            mirec_topk_trace[sw][t] = (unsigned)(t2 - t1);
-            mirec_topk_trace[9 + (sw & 3)][t] = (unsigned)(t1 - t0);
-            if (sw == 0 && t >= 1) {
-                mirec_topk_trace[13][t] = (unsigned)(dbg_a - t1);
-                mirec_topk_trace[14][t] = (unsigned)(dbg_b - dbg_a);
-                mirec_topk_trace[15][t] = (unsigned)(t2 - dbg_b);
-            }
+    // Item images: all wavefronts stage (global -> registers -> LDS); tile t + 2 goes to LDS during tile t, the
+    // loads of tile t + 3 are in flight meanwhile.
+    constexpr int NTS = 64 * NW;
+    constexpr int TILE_CH = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile
+    constexpr int NV = (TILE_CH + NTS - 1) / NTS;
+    tk_u32x4 pre[NV];
+    // Unconditional loads (a branch around a load makes the compiler wait for it on the spot): threads past
+    // the tile repeat its last chunk.
+    auto load_y = [&](int t) __attribute__((always_inline)) {
+        const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_CH;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int e = tid + v * NTS;
+            e = e < TILE_CH ? e : TILE_CH - 1;
+            pre[v] = src[e];
         }
-#endif
-    }
-#ifdef MIREC_DEBUG_TIMING
-    if (stid == 0) {
-        atomicAdd(&mirec_topk_dbg[4], ds);
-        atomicAdd(&mirec_topk_dbg[5], dsel);
-        atomicAdd(&mirec_topk_dbg[6], dbar);
-        atomicAdd(&mirec_topk_dbg[7], (unsigned long long)ntile);
-        atomicAdd(&mirec_topk_dbg[8], dst);
-    }
-#endif
-    mask_refill_commit();
-    if (ntile >= 1) select_tile(ntile - 1);
+    };
+    auto store_y = [&](char* ytile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int e = tid + v * NTS;
+            e = e < TILE_CH ? e : TILE_CH - 1;  // duplicates write the same values
+            const int row = e / F8;             // plane * 32 + item
+            const int kc = e % F8;
+            *reinterpret_cast<tk_u32x4*>(ytile + row * L::ROWB + 16 * kc) = pre[v];
+        }
+    };
+    // the caller guarantees at least two tiles; a tile past the last one repeats it (its image is never read)
+    load_y(0);
+    store_y(ybuf);
+    load_y(1);
+    store_y(ybuf + L::TILEB);
+    load_y(ntile > 2 ? 2 : ntile - 1);
+    store_y(ybuf + 2 * L::TILEB);
+    load_y(ntile > 3 ? 3 : ntile - 1);
+    __syncthreads();  // tiles 0 to 2 are staged, the progress words and fill counts are set
 
-    // ---- this selector's queries: margin set -> exact scores -> the k best
-    const unsigned long long t3 = TKS_T();
-    counts_to_lds();
-    for (int l = 0; l < 2 * NROW; ++l) {
-        const int ur = row_of(r0 + (l % NROW), l / NROW);
-        const int64_t ug = u0 + ur;
-        if (ug >= nq) continue;
-        const int n0 = __builtin_amdgcn_readfirstlane(st_cnt[ur]);
-        const float marg = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st_marg[ur])));
-        const bool hand_over = ((ovf >> ur) & 1u) || !(marg < INFINITY) || (mask_indptr != nullptr && n0 < k);
-        if (hand_over) {
-            if (lane == 0) qlist[atomicAdd(qcount, 1)] = (int32_t)ug;
-            continue;
+    // One candidate: reserve a slot of the query's buffer and fill it; false: the buffer is full.
+    auto append = [&](float s, int item) __attribute__((always_inline)) -> bool {
+        const int pos = atomicAdd(&cnt[q], 1);
+        if (pos < CAP) {
+            sel_s[pos * NQ + q] = s;
+            sel_i[pos * NQ + q] = item;
         }
-        float* ss = sel_s + ur * CAP;
-        int* ii = sel_i + ur * CAP;
-        float tnew;
-        bool over;
-        const int nm = compact_margin<CAP>(ss, ii, n0, k, lane, marg, CAP, tnew, over);
-        // exact score of every survivor: the fp32 chain s = fma(q[k], y[k], s), ascending k, from +0
-        for (int e0 = 0; e0 < nm; e0 += 64) {
-            const int e = e0 + lane;
-            const int id = e < nm ? ii[e] : 0;
-            const float* yr = Y + (int64_t)id * F;
-            const float* qr = Q + ug * F;
-            float s = 0.f;
-#pragma unroll 4
-            for (int k4 = 0; k4 < F / 4; ++k4) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(qr + 4 * k4);
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(yr + 4 * k4);
-                s = __builtin_fmaf(xv[0], yv[0], s);
-                s = __builtin_fmaf(xv[1], yv[1], s);
-                s = __builtin_fmaf(xv[2], yv[2], s);
-                s = __builtin_fmaf(xv[3], yv[3], s);
+        return pos < CAP;
+    };
+
+    // The matrix instructions of a tile are issued one tile ahead, between the steps of the selection over the
+    // previous tile's scores: the matrix pipe works on tile t + 1 while the vector and scalar units, the LDS and
+    // the branches of this same wavefront deal with tile t.
+    f32x16 acc0, acc1;
+    // A operands (item c of the tile, both planes) are fetched two k-steps ahead: the wait in front of a k-step's
+    // matrix instructions is for every LDS access in flight (the appends in between leave the compiler no
+    // other choice), so the newest fetch must be old by then
+    tk_u32x4 ya[3][TOPK_NPLANES];
+    const char* yb = ybuf + c * L::ROWB + 16 * h;
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < TOPK_NPLANES; ++p) ya[s % 3][p] = *reinterpret_cast<const tk_u32x4*>(yb + p * L::PLANEB + 32 * s);
+    };
+    auto kstep = [&](int s) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        const tk_u32x4(&a)[TOPK_NPLANES] = ya[s % 3];
+#ifdef MIREC_PROBE_TK_NOMFMA
+        acc0[s] += __uint_as_float(a[0][0] ^ qh[s][1]);
+        acc1[s] += __uint_as_float(a[1][2] ^ qm[s][3]);
+#else
+        // mid * mid is below 2^-18 of |q_k y_k| and left to the margin; the first use of an accumulator starts
+        // it from zero (an operand of the instruction, not a register fill)
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (s & 1) {
+            acc1 = tk_mma(a[0], qh[s], acc1);  // hi hi
+            acc0 = tk_mma(a[1], qh[s], acc0);  // mid hi
+            acc1 = tk_mma(a[0], qm[s], acc1);  // hi mid
+        } else {
+            acc0 = tk_mma(a[0], qh[s], s == 0 ? zero : acc0);
+            acc1 = tk_mma(a[1], qh[s], s == 0 ? zero : acc1);
+            acc0 = tk_mma(a[0], qm[s], acc0);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < KS) fetch(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // k-step s goes in front of selection step ceil(16 s / KS)
+    auto ksteps_before = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if ((16 * s + KS - 1) / KS == i) kstep(s);
+    };
+    fetch(0);
+    if (KS > 1) fetch(1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kstep(s);
+    if (lane == 0) tk_store_release(read_done + w, 1);
+
+    float sc[16];
+#ifdef MIREC_DEBUG_TIMING
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int t = 0; t < ntile; ++t) {
+        const int i0 = t * BI;
+        const unsigned long long c0 = TKS_T();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = acc0[i] + acc1[i];
+        if (t == ntile - 1) {  // rows past the last item
+            const int left = (int)(ni - i0) - 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = tk_rowpos(i) < left ? sc[i] : -INFINITY;
+        }
+        // the next tile (after the last one: the last one again, for nothing); every wavefront has stored its
+        // share of its image
+        const int tn = t + 1 < ntile ? t + 1 : t;
+        const unsigned long long c1 = TKS_T();
+#ifndef MIREC_PROBE_TK_NOSYNC
+        if (tn >= 3) tk_wait_all<NW>(staged, tn + 1, lane);
+#endif
+        const unsigned long long c2 = TKS_T();
+        yb = ybuf + (tn % PD) * L::TILEB + c * L::ROWB + 16 * h;
+        fetch(0);
+        if (KS > 1) fetch(1);
+
+        // liked items of the tile (walker lanes)
+#ifdef MIREC_PROBE_TK_NOWALK
+        const unsigned mw = 0u;
+#else
+        mask_refill_commit();
+        const unsigned mw = walk_tile(i0);
+#endif
+
+        const unsigned long long c3 = TKS_T();
+        float best4[4];  // of the four groups of four scores (items 8 g + 4 h .. + 3 of the tile)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) best4[g] = fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3]));
+        const float best = fmaxf(fmaxf(best4[0], best4[1]), fmaxf(best4[2], best4[3]));
+        unsigned fail = 0u;
+#ifdef MIREC_PROBE_TK_NOSCAN
+        if (best == 12345.f && __ballot(best > thr) != 0ull) {
+#else
+        if (__ballot(best > thr) != 0ull) {
+#endif
+            // liked bits of this lane's 16 items: bit tk_rowpos(i)
+            unsigned liked = 0u;
+            if (mask_indptr != nullptr) liked = (unsigned)__builtin_amdgcn_ds_bpermute(c << 2, (int)mw) >> (4 * h);
+            // candidates are few: a group of four scores is looked at only where its best beats the threshold
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int i = 4 * g; i < 4 * g + 4; ++i) ksteps_before(i);
+                if (best4[g] > thr) {
+#pragma unroll
+                    for (int i = 4 * g; i < 4 * g + 4; ++i) {
+                        if (sc[i] > thr && !((liked >> tk_rowpos(i)) & 1u)) {
+                            if (!append(sc[i], i0 + tk_rowpos(i) + 4 * h)) fail |= 1u << i;
+                        }
+                    }
+                }
             }
-            if (e < nm) ss[e] = s;
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) kstep(s);
         }
-        const int n = compact_sorted<CAP>(ss, ii, nm, k, lane);
-        for (int j = lane; j < k; j += 64) {
-            out_ids[ug * k + j] = j < n ? ii[j] : -1;
-            out_scores[ug * k + j] = j < n ? ss[j] : -FLT_MAX;
+        if (lane == 0) tk_store_release(read_done + w, tn + 1);  // this wavefront is done with the image of tile tn
+        const unsigned long long c4 = TKS_T();
+
+        // Buffers that were full: compact (every query of the wavefront, which raises all thresholds) and offer
+        // the candidates that were turned away again.  A second compaction covers a tile whose candidates
+        // alone overfill the space a compaction leaves; after that the query is given up.
+        // A compaction stops a wavefront for a few thousand cycles, more than the image ring absorbs, so the others
+        // end up waiting for it; at the tiles of a schedule that all wavefronts share (fill grows with the
+        // logarithm of the tile number: powers of two) every wavefront compacts, and the forced ones become rare.
+        auto compact = [&]() __attribute__((always_inline)) {
+            bool over;
+            tk_compact_all<CAP, NQ, L::LIMIT>(sel_s, sel_i, cnt, q, h, k, marg, thr, over);
+            if (over) {
+                ovf = true;
+                thr = INFINITY;
+            }
+        };
+        bool fresh = false;  // compacted since the last candidate was turned away
+        if (t >= 2 && (t & (t - 1)) == 0) {
+            compact();
+            fresh = true;
+        }
+        int offers = 0;
+        while (__ballot(fail != 0u) != 0ull) {
+            if (offers == 2) {
+                if (fail != 0u) {
+                    ovf = true;
+                    thr = INFINITY;
+                }
+                break;
+            }
+            ++offers;
+            if (!fresh) compact();
+            fresh = false;
+            const unsigned again = fail;
+            fail = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (((again >> i) & 1u) && sc[i] > thr) {
+                    if (!append(sc[i], i0 + tk_rowpos(i) + 4 * h)) fail |= 1u << i;
+                }
+            }
+        }
+
+        const unsigned long long c5 = TKS_T();
+        unsigned long long c6 = c5;
+        if (t + 3 < ntile) {
+            // the image that tile t + 3 replaces was that of tile t + 3 - PD: everybody must be done reading it
+#ifndef MIREC_PROBE_TK_NOSYNC
+            if (t + 4 - PD >= 1) tk_wait_all<NW>(read_done, t + 4 - PD, lane);
+#endif
+            c6 = TKS_T();
+            store_y(ybuf + ((t + 3) % PD) * L::TILEB);
+            if (lane == 0) tk_store_release(staged + w, t + 4);
+            load_y(t + 4 < ntile ? t + 4 : ntile - 1);
+        }
+#ifndef MIREC_PROBE_TK_NOWALK
+        mask_refill_issue();
+#endif
+        TKS_ADD(0, c1 - c0);           // scores out of the accumulators (waits for the matrix pipe)
+        TKS_ADD(1, c2 - c1);           // wait: next image staged
+        TKS_ADD(2, c3 - c2);           // liked-item walk
+        TKS_ADD(3, c4 - c3);           // selection steps + matrix instructions of the next tile
+        TKS_ADD(4, c5 - c4);           // compactions and second offers
+        TKS_ADD(5, c6 - c5);           // wait: image to be replaced is read
+        TKS_ADD(6, TKS_T() - c6);      // staging
+    }
+#ifdef MIREC_DEBUG_TIMING
+    const unsigned long long cf = TKS_T();
+#endif
+
+    // ---- margin set -> exact scores -> the k best, for the 32 queries of the wavefront
+    bool over;
+    int nfin = tk_compact_all<CAP, NQ, L::LIMIT>(sel_s, sel_i, cnt, q, h, k, marg, thr, over);
+    ovf = ovf || over;
+    {
+        const tk_pair_u32 po = tk_pair(ovf ? 1u : 0u);
+        ovf = (po.x | po.y) != 0u;
+    }
+    const bool hand_over = uv && (unfit || ovf || (mask_indptr != nullptr && nfin < k));
+    const bool answer = uv && !hand_over;
+    nfin = answer ? nfin : 0;
+    if (h == 0) {
+        if (hand_over) qlist[atomicAdd(qcount, 1)] = (int32_t)ug;
+        cnt[q] = answer ? nfin : -1;
+    }
+    // exact score of every survivor: the fp32 chain s = fma(q[k], y[k], s), ascending k, from +0.  The lane in
+    // half h takes the entries 2j + h of its query, whose row it keeps in registers.
+    {
+        f32x4 qv[F / 4];
+        const float* qr = Q + (uv ? ug : 0) * F;
+#pragma unroll
+        for (int k4 = 0; k4 < F / 4; ++k4) qv[k4] = *reinterpret_cast<const f32x4*>(qr + 4 * k4);
+        for (int j = 0;; ++j) {
+            const int e = 2 * j + h;
+            const bool act = e < nfin;
+            if (__ballot(act) == 0ull) break;
+            const int id = act ? sel_i[e * NQ + q] : 0;
+            const float* yr = Y + (int64_t)id * F;
+            float s = 0.f;
+            // the row in groups of G 16-byte loads, the next group in flight during the chain of the current one
+            constexpr int G = (F / 4) % 8 == 0 ? 8 : 4;
+            f32x4 yv[2][G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) yv[0][g] = *reinterpret_cast<const f32x4*>(yr + 4 * g);
+#pragma unroll
+            for (int k0 = 0; k0 < F / 4; k0 += G) {
+                const int b = (k0 / G) & 1;
+                if (k0 + G < F / 4) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) yv[b ^ 1][g] = *reinterpret_cast<const f32x4*>(yr + 4 * (k0 + G + g));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    s = __builtin_fmaf(qv[k0 + g][0], yv[b][g][0], s);
+                    s = __builtin_fmaf(qv[k0 + g][1], yv[b][g][1], s);
+                    s = __builtin_fmaf(qv[k0 + g][2], yv[b][g][2], s);
+                    s = __builtin_fmaf(qv[k0 + g][3], yv[b][g][3], s);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (act) sel_s[e * NQ + q] = s;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // Order and write: two queries at a time, one per half-wave, one survivor per lane (at most LIMIT <= 32):
+    // its rank under (score desc, item asc) is the number of survivors that are better.
+    for (int p = 0; p < 16; ++p) {
+        const int qq = w * 32 + 2 * p + h;
+        const int n2 = cnt[qq];  // -1: not answered here
+        const int nmax = max(__builtin_amdgcn_readlane(n2, 0), __builtin_amdgcn_readlane(n2, 32));
+        const bool mine = c < n2;
+        const float ms = mine ? sel_s[c * NQ + qq] : -INFINITY;
+        const int mi = mine ? sel_i[c * NQ + qq] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < nmax; ++j) {
+            const float sj = sel_s[j * NQ + qq];
+            const int ij = sel_i[j * NQ + qq];
+            rank += (j < n2 && better(sj, ij, ms, mi)) ? 1 : 0;
+        }
+        const int64_t uq = (int64_t)blockIdx.x * NQ + qq;
+        if (mine && rank < k) {
+            out_ids[uq * k + rank] = mi;
+            out_scores[uq * k + rank] = ms;
+        }
+        if (n2 >= 0 && c >= n2 && c < k) {  // fewer than k survivors: the tail is empty
+            out_ids[uq * k + c] = -1;
+            out_scores[uq * k + c] = -FLT_MAX;
         }
     }
 #ifdef MIREC_DEBUG_TIMING
-    if (stid == 0) atomicAdd(&mirec_topk_dbg[9], TKS_T() - t3);
+    if (tid == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&mirec_topk_dbg[i], dbg[i]);
+        atomicAdd(&mirec_topk_dbg[7], TKS_T() - cf);  // final stage
+        atomicAdd(&mirec_topk_dbg[8], (unsigned long long)ntile);
+    }
 #endif
 }
 
-template <int F, int WM, int CAP>
+template <int F, int NW, int CAP, int PD>
 static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
                                   const int32_t* mask_indices, int k, int32_t* out_ids, float* out_scores, void* ws,
                                   hipStream_t stream) {
-    using L = TopkPlanesLds<F, WM, CAP>;
+    using L = TopkPlanesLds<F, NW, CAP, PD>;
     static_assert(L::BYTES <= 160 * 1024, "top-K plane kernel: LDS image too large");
     static OncePerDevice once;  // idempotent; a race only repeats the call
     bool* attr_done = once.slot();
     MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
     if (!*attr_done) {
-        MIREC_HIP(hipFuncSetAttribute((const void*)topk_planes_kernel<F, WM, CAP>,
+        MIREC_HIP(hipFuncSetAttribute((const void*)topk_planes_kernel<F, NW, CAP, PD>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
         *attr_done = true;
     }
@@ -880,8 +812,8 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
     hipLaunchKernelGGL((topk_split_items_kernel<F>), dim3((unsigned)ntile), dim3(32 * (F / 8)), 0, stream, Y, ni, planes,
                        ymax_bits);
     MIREC_LAUNCH_CHECK();
-    const int64_t blocks = (nq + 32 * WM - 1) / (32 * WM);
-    hipLaunchKernelGGL((topk_planes_kernel<F, WM, CAP>), dim3((unsigned)blocks), dim3(64 * L::NW), L::BYTES, stream, Q, nq,
+    const int64_t blocks = (nq + L::NQ - 1) / L::NQ;
+    hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream, Q, nq,
                        Y, ni, planes, ymax_bits, mask_indptr, mask_indices, k, out_ids, out_scores, qlist, qcount);
     MIREC_LAUNCH_CHECK();
     // the queries handed over (none, as a rule): the fp32 kernel in list mode, sized for the worst case
@@ -901,8 +833,8 @@ int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const in
                           "mirec_topk: workspace of %zu bytes given, mirec_topk_workspace_bytes asks for %zu", ws_bytes,
                           topk_workspace_layout(nq, ni, F).bytes);
             MIREC_REQUIRE(((uintptr_t)ws & 255) == 0, MIREC_E_INVALID, "mirec_topk: workspace must be 256-byte aligned");
-            return launch_topk_planes_cfg<F, 4, 64>(Q, nq, Y, ni, mask_indptr, mask_indices, k, out_ids, out_scores, ws,
-                                                    stream);
+            return launch_topk_planes_cfg<F, 8, 48, 3>(Q, nq, Y, ni, mask_indptr, mask_indices, k, out_ids, out_scores, ws,
+                                                       stream);
         }
     }
     return launch_topk_fused<F>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids, out_scores, nullptr,
