@@ -350,10 +350,11 @@ def main():
         # of the score matrix) and re-score the survivors in fp32; everything else runs on the fp32 matrix pipe
         planes = W % 16 == 0 and W <= 128 and args.topk <= 24
         peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if planes else MFMA_F32_PEAK_TFLOPS
-        kname = ("topk_planes_kernel<%d,4,64>" % W) if planes else "topk_kernel<%d,%s>" % (
-            W, "4,56" if args.topk <= 24 else "4,128" if args.topk <= 96 else "2,256")
+        kname = ("topk_planes_kernel<%d, 8, 48, 3>" % W) if planes else "topk_kernel<%d, %s>" % (
+            W, "4, 56" if args.topk <= 24 else "4, 128" if args.topk <= 96 else "2, 256")
         extra["topk_roofline"] = {"kernel": kname, "bound": "mfma", "achieved": flops / tk / 1e12, "peak": peak,
                                   "unit": "TFLOP/s", "frac": flops / tk / 1e12 / peak,
+                                  "traffic": pmc_traffic("topk", kname) if args.topk == 20 else None,
                                   "note": "achieved = 2*users*items*f / time; peak = dense bf16 peak / 3 plane products"
                                   if planes else "achieved = 2*users*items*f / time; peak = dense fp32 matrix peak"}
         del outs
