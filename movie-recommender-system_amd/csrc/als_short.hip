@@ -550,6 +550,18 @@ __device__ __forceinline__ sm_f32x2 sm_scale_for(float bound) {
 #ifndef MIREC_SHORT_RS
 #define MIREC_SHORT_RS 1
 #endif
+// Wavefronts of the workgroup (two of them servers).  The kernel's rate follows the number of solvers, not the
+// number of gathered rows they can keep on chip: 8 wavefronts of 256 registers with 60 / 92 / 108 rows on chip
+// (RS = 1 / 3 / 4) ran the 1 M x 27 k user half-sweep in 7.9 / 7.5 / 7.7 ms, 10 wavefronts in 6.5 ms, 12 in 6.2 ms.
+#ifndef MIREC_SHORT_NW
+#define MIREC_SHORT_NW 12
+#endif
+// A server sweeps when this many vectors wait (or every solver that still has rows has published).  Smaller
+// batches shorten the first publisher's wait and lengthen everybody else's: 3 / 5 / 7 / 9 gave 6.5 / 6.9 / 7.0 /
+// 7.0 ms against 6.2 ms for "all".
+#ifndef MIREC_SRV_MIN_BATCH
+#define MIREC_SRV_MIN_BATCH 16
+#endif
 // A server starts a sweep when every solver that still has rows has published, or after this many polls with at
 // least one vector waiting (a bound, so that the loop ends whatever the solvers do; with it reached the sweep
 // serves those that wait -- any split of the vectors over sweeps gives the same results).
@@ -561,7 +573,7 @@ template <int NT>
 struct MfmaShort {
     static_assert(NT == 2 || NT == 4, "matrix-core G v: widths 64 and 128");
     static constexpr int F = 32 * NT;
-    static constexpr int NW = 12;               // wavefronts of the workgroup: three per SIMD, 168 registers each
+    static constexpr int NW = MIREC_SHORT_NW;   // wavefronts of the workgroup: three per SIMD, 168 registers each
     static constexpr int NSRV = 2;              // servers (the last wavefronts)
     static constexpr int NS = NW - NSRV;        // solvers
     static constexpr int COLS = 16;             // columns of a matrix instruction (NS of them used)
@@ -717,7 +729,9 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
         // the same time: wait until every solver that still has rows has published, and one sweep serves them
         // all.  Sweeps for one or two vectors each would cost the matrix pipe as much as a full one, and there
         // would be six times as many (measured on 1 M x 27 k users: 7.5 ms against 6.6 ms for the half-sweep).
-        if (__builtin_popcount(waiting) < M::NS - nfin && ++polls <= MIREC_SRV_MAX_POLLS) {
+        const int active = M::NS - nfin;
+        if (__builtin_popcount(waiting) < (active < MIREC_SRV_MIN_BATCH ? active : MIREC_SRV_MIN_BATCH) &&
+            ++polls <= MIREC_SRV_MAX_POLLS) {
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
@@ -756,6 +770,19 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
     }
 }
 
+// Optional phase timing (-DMIREC_DEBUG_TIMING): cycle counts of the phases of a row, of the first solver of every
+// workgroup, summed into a counter array that mirec_short_debug_read returns (tools/probes/short_phase_timing.py).
+// 1 M x 27 k user half-sweep, per row of 35 k cycles: header 1.0 k, four publishes 2.0 k, first pass 7.5 k, four
+// waits for the servers 8.9 k, three later passes 12.8 k, vector updates 1.3 k.
+#ifdef MIREC_DEBUG_TIMING
+static __device__ unsigned long long mirec_short_dbg[16];
+#define SHT_T() __builtin_readcyclecounter()
+#define SHT_ADD(i, v) sdbg[i] += (v)
+#else
+#define SHT_T() 0ull
+#define SHT_ADD(i, v)
+#endif
+
 template <int NT, bool BIG>
 __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
@@ -783,9 +810,13 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
     float* cache = smem + M::CACHE + w * (CAP * F);
     int seq = 0;  // products this solver has published
 
+#ifdef MIREC_DEBUG_TIMING
+    unsigned long long sdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // the solvers of a workgroup take consecutive rows of the plan's list (rows of about equal length)
     const int64_t stride = (int64_t)gridDim.x * M::NS;
     for (int64_t r = (int64_t)blockIdx.x * M::NS + w; r < n_short; r += stride) {
+        const unsigned long long s0 = SHT_T();
         const int64_t row = row_begin + order[r];
         const int64_t rs = indptr[row];
         const int n = (int)(indptr[row + 1] - rs);
@@ -806,9 +837,18 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
         float part = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) part = fmaf(x[t], x[t], part);
+        const unsigned long long s1 = SHT_T();
         float unscale = symv_publish<NT>(smem, x, sqrtf(half_sum(part)), w, ++seq, lane, h, c) * gsc[1];
+        const unsigned long long s2 = SHT_T();
         sparse_pass<NT, CAP, true, BIG, RS>(x, acc, ind, dat, Y, cache, n, lane, h, c, R);
+        const unsigned long long s3 = SHT_T();
         symv_collect<NT>(smem, x, Ap, unscale, w, seq, c);
+        const unsigned long long s4 = SHT_T();
+        SHT_ADD(0, s1 - s0);  // row header, x, norm
+        SHT_ADD(1, s2 - s1);  // publish
+        SHT_ADD(2, s3 - s2);  // first pass (gathers)
+        SHT_ADD(3, s4 - s3);  // collect (wait for the servers)
+        SHT_ADD(7, 1);
         part = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -820,9 +860,16 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
         if (rsold < 1e-20f) continue;
         float pbound = sqrtf(rsold) * 1.0001f;  // |p| for p = r; afterwards |r + beta p| <= |r| + beta |p|
         for (int it = 0; it < cg_steps; ++it) {
+            const unsigned long long c0 = SHT_T();
             unscale = symv_publish<NT>(smem, p, pbound, w, ++seq, lane, h, c) * gsc[1];
+            const unsigned long long c1 = SHT_T();
             sparse_pass<NT, CAP, false, BIG, RS>(p, acc, ind, dat, Y, cache, n, lane, h, c, R);
+            const unsigned long long c2 = SHT_T();
             symv_collect<NT>(smem, p, Ap, unscale, w, seq, c);
+            const unsigned long long c3 = SHT_T();
+            SHT_ADD(1, c1 - c0);
+            SHT_ADD(4, c2 - c1);  // later passes
+            SHT_ADD(3, c3 - c2);
             part = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -844,9 +891,15 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
             for (int t = 0; t < NT; ++t) p[t] = fmaf(beta, p[t], rr[t]);
             pbound = (sqrtf(rsnew) + fabsf(beta) * pbound) * 1.0001f;
             rsold = rsnew;
+            SHT_ADD(5, SHT_T() - c3);  // vector updates of a CG step
         }
         if (h == 0) store_n<NT>(xg, x);
+        SHT_ADD(6, SHT_T() - s0);  // whole row
     }
+#ifdef MIREC_DEBUG_TIMING
+    if (w == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&mirec_short_dbg[i], sdbg[i]);
+#endif
     // every product this solver published has been collected: the servers may stop once all solvers are here
     if (lane == 0) __hip_atomic_fetch_add(flags + 32, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -958,3 +1011,14 @@ int als_short_cache_rows(int nt) {
 }
 
 }  // namespace mirec
+
+#ifdef MIREC_DEBUG_TIMING
+extern "C" int mirec_short_debug_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mirec::mirec_short_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mirec::mirec_short_dbg), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif
