@@ -235,6 +235,27 @@ def test_sharded_driver_with_shards_without_rows(dev, world, users, items):
         assert held < 0.6 * whole, res.stdout[-500:]
 
 
+@pytest.mark.timeout(300)
+def test_rccl_takes_the_drivers_collectives_on_one_rank(dev):
+    """RCCL with a single rank (what one GPU allows): the backend initialises and accepts the collectives in the
+    form the sharded driver issues them (tools/rccl_one_rank_check.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "tools", "rccl_one_rank_check.py")], capture_output=True, text=True,
+                         timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "rccl one-rank collectives: ok" in res.stdout
+
+
 def sampled_parity_run(dev, U, I, mean_degree, seed, f, user_samples, item_samples, with_loss, topk_samples=0,
                        arbitrate_later_sweeps=False):
     """Two device iterations over a synthetic matrix; after every half-sweep a sample of the solved rows (random
