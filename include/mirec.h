@@ -115,8 +115,17 @@ int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, mir
  *               so that every shard of a multi-GPU fit scales alike; an upper
  *               bound does; 0 = not known: the sweep then finds it with one pass
  *               over the values of its rows
+ *   cg_steps    >= 0: that many conjugate-gradient steps from the warm start;
+ *               MIREC_SOLVE_EXACT: solve A_u x = b_u exactly instead (implicit's
+ *               use_cg=False path, `_least_squares`: LAPACK posv) by an fp32
+ *               Cholesky factorisation in the explicit-Gram kernels; the plan must
+ *               then be built with short_max = 0, so that every row with entries
+ *               takes that kernel.  A row whose A_u is not positive definite
+ *               (possible only with confidences below 1) comes out as NaN; the
+ *               library's LU fallback for that case is not reproduced.
  * A sweep over an empty row range (row_begin == row_end: a shard that owns no
  * rows) returns MIREC_OK without reading any other argument. */
+#define MIREC_SOLVE_EXACT (-1)
 int mirec_als_short_cache_rows(int f);
 size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk_nnz);
 int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_end, int64_t nnz, int f,

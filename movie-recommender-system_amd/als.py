@@ -49,7 +49,12 @@ def _hide_filtered(ids: torch.Tensor, scores: torch.Tensor, mask) -> torch.Tenso
 class AlternatingLeastSquares:
     """Implicit-feedback ALS (Hu, Koren, Volinsky) with the conjugate-gradient
     solver of Takacs, Pilaszy and Tikk: ``cg_steps`` (3) warm-started steps per
-    row per half-sweep."""
+    row per half-sweep.  ``use_cg=False`` selects implicit's exact solver
+    instead (``_least_squares``: the normal equations of every row by
+    Cholesky); it needs every stored value times ``alpha`` to be at least 1 in
+    magnitude, which keeps the row systems positive definite."""
+
+    SOLVE_EXACT = -1   # MIREC_SOLVE_EXACT of the C ABI
 
     def __init__(self, factors: int = 100, regularization: float = 0.01, alpha: float = 1.0, dtype=np.float32,
                  use_native: bool = True, use_cg: bool = True, use_gpu: bool = True, iterations: int = 15,
@@ -57,8 +62,6 @@ class AlternatingLeastSquares:
                  cg_steps: int = 3, device=None):
         if np.dtype(dtype) != np.float32:
             raise ValueError("only float32 factors are supported")
-        if not use_cg:
-            raise NotImplementedError("the exact (use_cg=False) solver is not built; use_cg=True is implicit's default")
         self.factors = int(factors)
         self.regularization = float(regularization)
         self.alpha = float(alpha)
@@ -123,7 +126,14 @@ class AlternatingLeastSquares:
             dCui = E.DeviceCSR.from_scipy(Cui, dev, scale=self.alpha)
             X = E.pad_factors(self.user_factors, F, dev)
             Y = E.pad_factors(self.item_factors, F, dev)
-            eng = E.AlsEngine(dCui, None, X, Y, self.regularization, self.cg_steps)
+            if self.use_cg:
+                eng = E.AlsEngine(dCui, None, X, Y, self.regularization, self.cg_steps)
+            else:
+                if Cui.nnz and float(np.abs(Cui.data).min()) * abs(self.alpha) < 1.0:
+                    raise ValueError("use_cg=False needs |value| * alpha >= 1 for every stored entry "
+                                     "(smaller confidences can make a row's system indefinite)")
+                # every row with entries goes through the explicit-Gram kernel, which holds the Cholesky solve
+                eng = E.AlsEngine(dCui, None, X, Y, self.regularization, self.SOLVE_EXACT, short_max=0)
             for it in range(self.iterations):
                 eng.iteration()
                 if callback is not None:

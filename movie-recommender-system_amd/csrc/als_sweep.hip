@@ -279,6 +279,136 @@ __device__ void cg_solve_block(const float* A, const float* b, float* vec, float
     }
 }
 
+// Exact solve of the explicit system (implicit's use_cg=False path, cpu/_als.pyx `_least_squares`: LAPACK posv),
+// run by all NTHR threads of the workgroup (every thread must call it): A x = b by a Cholesky factorisation
+// A = L L^T, x written to global memory.  The warm start plays no part.
+//   A     LDS, row stride F + 1 (so that a column is as free of bank conflicts as a row), lower triangle read
+//   col   LDS scratch of 2 (F + 4) floats, 16-byte aligned;  dinv: LDS scratch of F floats
+// The lower triangle is cut into 4 x 4 blocks that live in registers, one or a few per thread; b rides along as one
+// more row of the matrix (row F: after the factorisation it holds z = L^-1 b, so the forward substitution costs
+// nothing).  Right-looking, one workgroup barrier per column: the owners of block column j / 4 publish column j as
+// it stands after the updates of columns < j; after the barrier every thread scales the entries it needs by
+// 1 / sqrt(a_jj) itself and updates its blocks a_ik -= l_ij l_kj.  Two column buffers alternate, so a thread that
+// is one column ahead never overwrites what a slower one still reads.  The back substitution L^T x = z runs on
+// wavefront 0 from L in LDS, one column per step.  A pivot that is not positive (A not positive definite, possible
+// only with confidences below 1) yields NaN in that row; LAPACK's LU fallback is not reproduced.
+template <int F, int NTHR>
+__device__ void chol_solve_block(float* A, const float* b, float* col, float* dinv, float* xg, int tid) {
+    constexpr int LDA = F + 1;
+    constexpr int NBLK = F / 4;
+    constexpr int NTRI = NBLK * (NBLK + 1) / 2;
+    constexpr int NB = NTRI + NBLK;               // + the blocks of the row that carries b
+    constexpr int NBK = (NB + NTHR - 1) / NTHR;   // blocks per thread
+    constexpr int CB = F + 4;                     // floats of one column buffer
+    float a[NBK][4][4];
+    int bi[NBK], bj[NBK];  // block row / block column; bi == NBLK: the b row; bj == -1: no block
+    // Blocks are numbered column by column (block column c holds rows c .. NBLK, the last being b's), so that the
+    // threads of a wavefront own neighbouring block columns and the whole wavefront falls idle once the
+    // factorisation has passed them: the work of a column shrinks with the trailing matrix.
+#pragma unroll
+    for (int s = 0; s < NBK; ++s) {
+        const int id = tid + s * NTHR;
+        bi[s] = 0;
+        bj[s] = -1;
+        if (id < NB) {
+            // first id of block column c: c (NBLK + 1) - c (c - 1) / 2
+            const float h = (float)NBLK + 1.5f;
+            int c = (int)(h - sqrtf(h * h - 2.f * (float)id));
+            c = c < 0 ? 0 : (c > NBLK - 1 ? NBLK - 1 : c);
+            while (c > 0 && c * (NBLK + 1) - c * (c - 1) / 2 > id) --c;
+            while (c < NBLK - 1 && (c + 1) * (NBLK + 1) - (c + 1) * c / 2 <= id) ++c;
+            bj[s] = c;
+            bi[s] = c + (id - (c * (NBLK + 1) - c * (c - 1) / 2));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = 0.f;
+                if (bj[s] >= 0) {
+                    if (bi[s] < NBLK) v = A[(4 * bi[s] + r) * LDA + 4 * bj[s] + c];
+                    else if (r == 0) v = b[4 * bj[s] + c];
+                }
+                a[s][r][c] = v;
+            }
+    }
+    for (int cj = 0; cj < NBLK; ++cj) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * cj + jj;
+            float* cb = col + (jj & 1) * CB;
+#pragma unroll
+            for (int s = 0; s < NBK; ++s)
+                if (bj[s] == cj)
+                    *reinterpret_cast<float4*>(cb + 4 * bi[s]) = make_float4(a[s][0][jj], a[s][1][jj], a[s][2][jj], a[s][3][jj]);
+            __syncthreads();
+            // 1 / sqrt(a_jj): the hardware estimate and one Newton step (a non-positive pivot gives NaN)
+            const float dj = cb[j];
+            float inv = __builtin_amdgcn_rsqf(dj);
+            inv = inv * fmaf(-0.5f * dj * inv, inv, 1.5f);
+            if (tid == 0) dinv[j] = inv;
+#pragma unroll
+            for (int s = 0; s < NBK; ++s) {
+                if (bj[s] < cj) continue;
+                const float4 ri = *reinterpret_cast<const float4*>(cb + 4 * bi[s]);
+                const float4 rk = *reinterpret_cast<const float4*>(cb + 4 * bj[s]);
+                const float li[4] = {ri.x * inv, ri.y * inv, ri.z * inv, ri.w * inv};
+                const float lk[4] = {rk.x * inv, rk.y * inv, rk.z * inv, rk.w * inv};
+                if (bj[s] == cj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int c = jj + 1; c < 4; ++c) a[s][r][c] = fmaf(-li[r], lk[c], a[s][r][c]);
+                        a[s][r][jj] = li[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a[s][r][c] = fmaf(-li[r], lk[c], a[s][r][c]);
+                }
+            }
+        }
+    }
+    // L (rows below the diagonal are what the back substitution reads) and z to LDS
+    __syncthreads();  // the last column buffer is read by all before z overwrites buffer 0
+#pragma unroll
+    for (int s = 0; s < NBK; ++s) {
+        if (bj[s] < 0) continue;
+        if (bi[s] < NBLK) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) A[(4 * bi[s] + r) * LDA + 4 * bj[s] + c] = a[s][r][c];
+        } else {
+            *reinterpret_cast<float4*>(col + 4 * bj[s]) = make_float4(a[s][0][0], a[s][0][1], a[s][0][2], a[s][0][3]);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        constexpr int NC = (F + 63) / 64;
+        const int lane = tid;
+        float z[NC];
+#pragma unroll
+        for (int m = 0; m < NC; ++m) z[m] = (lane + 64 * m < F) ? col[lane + 64 * m] : 0.f;
+        for (int i = F - 1; i >= 0; --i) {
+            float zi = z[0];
+#pragma unroll
+            for (int m = 1; m < NC; ++m) zi = (i >> 6) == m ? z[m] : zi;
+            const float xi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(zi), i & 63)) * dinv[i];
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                const int jc = lane + 64 * m;
+                const float l = A[i * LDA + (jc < F ? jc : F - 1)];
+                z[m] = jc < i ? fmaf(-l, xi, z[m]) : (jc == i ? xi : z[m]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
+            if (lane + 64 * m < F) xg[lane + 64 * m] = z[m];
+    }
+}
+
 // Optional in-kernel phase timing (-DMIREC_DEBUG_TIMING): per-wave cycle counts summed into mirec_dbg and
 // read back with mirec_debug_read; tools/probes/gram_phase_timing.py prints them.
 #ifdef MIREC_DEBUG_TIMING
@@ -320,7 +450,8 @@ struct GramCfg {
     static constexpr int PLANE_BYTES = F * 64;
     static constexpr int TILE_BYTES = NPLANES * PLANE_BYTES;
     static constexpr int TILE_FLOATS = TILE_BYTES / 4;
-    static constexpr int BIGN = (F * F > 2 * TILE_FLOATS) ? F * F : 2 * TILE_FLOATS;
+    static constexpr int LDX = F + 1;  // row stride of A for the exact solver (columns free of bank conflicts)
+    static constexpr int BIGN = (F * LDX > 2 * TILE_FLOATS) ? F * LDX : 2 * TILE_FLOATS;
     static constexpr int PART_STRIDE = NTILES * 256 + F;  // floats of one partial-result slot
     // LDS map (floats): [0, BIGN) gather tiles / A; sign masks of the two tiles; b partials of the four entry
     // groups; b; the CG work vector; the CG partial products
@@ -627,7 +758,7 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
 // producers).
 template <int NT, int W>
 __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int ntiles, float* smem, bool single,
-                                              float* P, int lane, float unscale) {
+                                              float* P, int lane, float unscale, int lda) {
     using C = GramCfg<NT>;
     using WA = WaveAcc<NT, W>;
     constexpr int F = C::F;
@@ -671,8 +802,8 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
             for (int e = 0; e < 4; ++e) {
                 const int rr = W * 16 + q * 4 + e, cc = (W + j) * 16 + i;
                 const float v = A.a0[j][e] * unscale;
-                big[rr * F + cc] = v + G[rr * F + cc];
-                if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
+                big[rr * lda + cc] = v + G[rr * F + cc];
+                if (j > 0) big[cc * lda + rr] = v + G[cc * F + rr];
             }
 #pragma unroll
         for (int j = 0; j < WA::N1; ++j)
@@ -680,8 +811,8 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
             for (int e = 0; e < 4; ++e) {
                 const int rr = WA::R1 * 16 + q * 4 + e, cc = (WA::R1 + j) * 16 + i;
                 const float v = A.a1[j][e] * unscale;
-                big[rr * F + cc] = v + G[rr * F + cc];
-                if (j > 0) big[cc * F + rr] = v + G[cc * F + rr];
+                big[rr * lda + cc] = v + G[rr * F + cc];
+                if (j > 0) big[cc * lda + rr] = v + G[cc * F + rr];
             }
     } else {
         // upper tiles only, tile-major: slot[tile][row][col]
@@ -762,14 +893,16 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
         sc = gram_scale(gmax, conf_max > 0.f ? conf_max : *conf_max_dev);
     }
     const float scale2 = sc[0] * sc[0], unscale = sc[1];
+    const bool exact = cg_steps < 0;          // Cholesky instead of conjugate gradients
+    const int lda = exact ? C::LDX : F;
 
     switch (w) {
-        case 0: gram_consumer<NT, 0>(G, ntiles, smem, single, P, lane, unscale); break;
-        case 1: if constexpr (NT > 1) gram_consumer<NT, 1>(G, ntiles, smem, single, P, lane, unscale); break;
-        case 2: if constexpr (NT > 2) gram_consumer<NT, 2>(G, ntiles, smem, single, P, lane, unscale); break;
-        case 3: if constexpr (NT > 3) gram_consumer<NT, 3>(G, ntiles, smem, single, P, lane, unscale); break;
-        case 4: if constexpr (NT > 4) gram_consumer<NT, 4>(G, ntiles, smem, single, P, lane, unscale); break;
-        case 5: if constexpr (NT > 5) gram_consumer<NT, 5>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 0: gram_consumer<NT, 0>(G, ntiles, smem, single, P, lane, unscale, lda); break;
+        case 1: if constexpr (NT > 1) gram_consumer<NT, 1>(G, ntiles, smem, single, P, lane, unscale, lda); break;
+        case 2: if constexpr (NT > 2) gram_consumer<NT, 2>(G, ntiles, smem, single, P, lane, unscale, lda); break;
+        case 3: if constexpr (NT > 3) gram_consumer<NT, 3>(G, ntiles, smem, single, P, lane, unscale, lda); break;
+        case 4: if constexpr (NT > 4) gram_consumer<NT, 4>(G, ntiles, smem, single, P, lane, unscale, lda); break;
+        case 5: if constexpr (NT > 5) gram_consumer<NT, 5>(G, ntiles, smem, single, P, lane, unscale, lda); break;
     }
     if (w >= NT) gram_producer<NT, BIG>(indices, data, Y, ks, ke, smem, tid - 64 * NT, scale2);
     __syncthreads();  // A (or the partial slot) and the b partials of the four entry groups are written
@@ -781,7 +914,8 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     }
     if (single) {
         __syncthreads();
-        cg_solve_block<F, 2 * NT>(big, bvec, vec, smem + C::CGP, xrow, cg_steps, tid);
+        if (exact) chol_solve_block<F, NTHR>(big, bvec, bred, vec, xrow, tid);
+        else cg_solve_block<F, 2 * NT>(big, bvec, vec, smem + C::CGP, xrow, cg_steps, tid);
     }
 #ifdef MIREC_DEBUG_TIMING
     if (tid == 0) {
@@ -807,6 +941,8 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
     float* vec = smem + C::VEC;
 
     const int tid = threadIdx.x;
+    const bool exact = cg_steps < 0;
+    const int lda = exact ? C::LDX : F;
     const int r = multi_row[blockIdx.x];
     const int nch = chunk_ptr[r + 1] - chunk_ptr[r];
     const float* P = partials + (size_t)mslot_ptr[r] * C::PART_STRIDE;
@@ -841,12 +977,13 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
             }
             const int bj = bi + (t - t0);
             const int rr = bi * 16 + rr16, cc = bj * 16 + cc16;
-            big[rr * F + cc] = s + G[rr * F + cc];
-            if (bj > bi) big[cc * F + rr] = s + G[cc * F + rr];
+            big[rr * lda + cc] = s + G[rr * F + cc];
+            if (bj > bi) big[cc * lda + rr] = s + G[cc * F + rr];
         }
     }
     __syncthreads();
-    cg_solve_block<F, NT>(big, bvec, vec, smem + C::CGP, X + (row_begin + r) * F, cg_steps, tid);
+    if (exact) chol_solve_block<F, C::NTHR>(big, bvec, smem + C::BRED, vec, X + (row_begin + r) * F, tid);
+    else cg_solve_block<F, NT>(big, bvec, vec, smem + C::CGP, X + (row_begin + r) * F, cg_steps, tid);
 }
 
 // Largest |confidence| over the stored entries of rows [row_begin, row_end) (non-negative floats order like their
@@ -1019,7 +1156,12 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     if (row_end == row_begin) return MIREC_OK;  // a shard without rows (its X block may be a null pointer)
     MIREC_REQUIRE(indptr && X && Y && G && plan && host_counts, MIREC_E_INVALID, "mirec_als_half_sweep: null argument");
     MIREC_REQUIRE(nnz == 0 || (indices && data), MIREC_E_INVALID, "mirec_als_half_sweep: null indices/data");
-    MIREC_REQUIRE(row_end >= row_begin && cg_steps >= 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad range or cg_steps");
+    MIREC_REQUIRE(row_end >= row_begin && cg_steps >= MIREC_SOLVE_EXACT, MIREC_E_INVALID,
+                  "mirec_als_half_sweep: bad range or cg_steps");
+    // the exact solver lives in the explicit-Gram kernels only: the plan must leave nothing but empty rows to the other
+    MIREC_REQUIRE(cg_steps >= 0 || short_max <= 0, MIREC_E_INVALID,
+                  "mirec_als_half_sweep: cg_steps = MIREC_SOLVE_EXACT needs a plan built with short_max = 0 (got %d)",
+                  short_max);
     MIREC_REQUIRE(f % 32 == 0 && f >= 32 && f <= 192, MIREC_E_UNSUPPORTED,
                   "mirec_als_half_sweep: factor width %d is not a multiple of 32 in [32,192]; zero-pad the columns", f);
     MIREC_REQUIRE(chunk_nnz > 0, MIREC_E_INVALID, "mirec_als_half_sweep: bad chunk_nnz %d", chunk_nnz);

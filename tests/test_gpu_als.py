@@ -96,6 +96,86 @@ def test_half_sweep_matches_oracle(dev, f, chunk, short_max):
     assert np.array_equal(dX3.cpu().numpy(), out)
 
 
+def _posv_f32(C, Y, reg):
+    """The exact solve the way implicit's `_least_squares` does it: LAPACK sposv on the fp32 system of every row
+    (scipy's assume_a="pos" solver is that routine).  The systems are accumulated in fp64 and rounded once."""
+    import scipy.linalg as sl
+    f = Y.shape[1]
+    Y64 = Y.astype(np.float64)
+    G = Y64.T @ Y64 + reg * np.eye(f)
+    out = np.zeros((C.shape[0], f), dtype=np.float32)
+    for u in range(C.shape[0]):
+        s, e = C.indptr[u], C.indptr[u + 1]
+        if s == e:
+            continue
+        y = Y64[C.indices[s:e]]
+        c = C.data[s:e].astype(np.float64)
+        A = G + (y * (np.abs(c) - 1.0)[:, None]).T @ y
+        b = (y * np.maximum(c, 0.0)[:, None]).sum(0)
+        out[u] = sl.solve(A.astype(np.float32), b.astype(np.float32), assume_a="pos")
+    return out
+
+
+@pytest.mark.parametrize("f", [32, 64, 96, 128, 160, 192])
+@pytest.mark.parametrize("chunk", [32, 0])
+def test_exact_half_sweep_matches_cholesky(dev, f, chunk):
+    """cg_steps = MIREC_SOLVE_EXACT (implicit's use_cg=False): every row's normal equations solved by an fp32
+    Cholesky factorisation on the device.  Judged against the float64-carried solve of the oracle; the bar is the
+    error LAPACK's fp32 posv makes on the same systems (x4, floor 1e-5), which moves with their conditioning.
+    Single-chunk rows, rows split over chunks (the finalize kernel), empty rows, negative stored values."""
+    import torch
+    from movie_recommender_system_amd import engine as E, _lib
+    rng = np.random.default_rng(900 + f + chunk)
+    rows, cols = 257, 190
+    C = random_csr(rng, rows, cols, 0.06, empty_rows=(0, 13, 256), heavy_rows=(5, 100))
+    C.data[:] = rng.uniform(1.0, 40.0, size=C.nnz).astype(np.float32)
+    C.data[rng.random(C.nnz) < 0.2] *= -1       # "confidence |c|, preference 0"
+    X = (rng.random((rows, f)) * 0.1).astype(np.float32)
+    Y = (rng.standard_normal((cols, f)) * 0.1).astype(np.float32)
+    X64 = X.copy()
+    oracle.als_half_sweep_exact(C, X64, Y, 0.01)
+    X32 = _posv_f32(C, Y, 0.01)
+    dC = E.DeviceCSR.from_scipy(C, dev)
+    dX, dY = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev)
+    G = E.gram(dY, 0.01)
+    plan = E.SweepPlan(dC, f, chunk, 0)
+    if chunk:
+        assert plan.n_split_rows >= 2
+    plan.sweep(dX, dY, G, -1)
+    out = dX.cpu().numpy()
+    assert np.all(np.isfinite(out)) and np.all(out[[0, 13, 256]] == 0.0)
+    e_dev, e_lapack = rel(out, X64), rel(X32, X64)
+    print(f"exact solve f={f} chunk={chunk}: device {e_dev:.2e}, fp32 posv {e_lapack:.2e} from float64")
+    assert e_dev <= max(4 * e_lapack, 1e-5)
+    # per row as well: no row may be far off where LAPACK is not
+    rd = np.linalg.norm(out - X64, axis=1) / np.maximum(np.linalg.norm(X64, axis=1), 1e-30)
+    rl = np.linalg.norm(X32 - X64, axis=1) / np.maximum(np.linalg.norm(X64, axis=1), 1e-30)
+    assert np.all(rd <= np.maximum(10 * rl.max(), 1e-4))
+    dX2 = torch.from_numpy(X).to(dev)
+    plan.sweep(dX2, dY, G, -1)
+    assert np.array_equal(dX2.cpu().numpy(), out)
+    # a plan that leaves rows to the matrix-free kernel cannot run the exact solve
+    with pytest.raises(_lib.MirecError):
+        E.SweepPlan(dC, f, chunk, 16).sweep(dX2, dY, G, -1)
+
+
+def test_exact_fit_matches_oracle(dev):
+    """AlternatingLeastSquares(use_cg=False): three iterations of exact half-sweeps against the oracle's."""
+    from movie_recommender_system_amd import AlternatingLeastSquares
+    rng = np.random.default_rng(77)
+    M = random_csr(rng, 400, 150, 0.08)
+    M.data[:] = 1.0
+    Xo, Yo = oracle.als_fit(M, factors=64, regularization=0.01, alpha=40, iterations=3, random_state=3, use_cg=False)
+    model = AlternatingLeastSquares(factors=64, regularization=0.01, alpha=40, iterations=3, random_state=3,
+                                    use_cg=False)
+    model.fit(M, show_progress=False)
+    eu, ei = rel(model.user_factors, Xo), rel(model.item_factors, Yo)
+    print(f"exact fit: users {eu:.2e}, items {ei:.2e} from the float64-carried oracle")
+    assert eu < 1e-4 and ei < 1e-4
+    with pytest.raises(ValueError):
+        AlternatingLeastSquares(factors=64, alpha=0.5, iterations=1, use_cg=False).fit(M, show_progress=False)
+
+
 def test_half_sweep_row_range(dev):
     """A plan over a row slice touches only its rows."""
     import torch

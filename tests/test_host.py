@@ -198,8 +198,9 @@ def test_model_state_is_plain_numpy():
     assert clone.factors == 3 and clone.regularization == 0.5 and clone.iterations == 7 and clone.random_state == 9
     assert np.array_equal(clone.user_factors, model.user_factors)
     assert clone.item_norms.tolist() == [1e-10] * 4 or np.allclose(clone.item_norms, 1e-10)
-    with pytest.raises(NotImplementedError):
-        AlternatingLeastSquares(use_cg=False)
+    # the exact solver is an option of the model, carried through the pickle like the others
+    exact = pickle.loads(pickle.dumps(AlternatingLeastSquares(use_cg=False)))
+    assert exact.use_cg is False and clone.use_cg is True
 
 
 def test_lightfm_request_path_signature_and_cold_start_draw():
