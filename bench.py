@@ -80,6 +80,8 @@ def cpu_baseline(Cu, Ci, users, items, nnz, f, reg, budget_s, seed):
     CSR of (leading) user rows and item rows; only the sampled rows are downloaded."""
     import oracle
 
+    # timed, never compared here: the AVX-512 build of the oracle where the host has AVX-512
+    march = oracle.use_widest_build()
     threads = oracle.num_threads()
     rs = np.random.RandomState(seed)
     # factors of the benchmark's start; only their size matters for the time
@@ -112,7 +114,7 @@ def cpu_baseline(Cu, Ci, users, items, nnz, f, reg, budget_s, seed):
     return {
         "value": est, "unit": "s/iteration", "cores": threads, "kind": "port",
         "sample": (f"oracle half-sweeps (restatement of implicit 0.7.2 CG, plain C loops built with gcc -O3 "
-                   f"-march=x86-64-v3, OpenMP {threads} threads) on "
+                   f"-march={march}, OpenMP {threads} threads) on "
                    f"{rows_u} user rows ({nnz_u} entries, {tu:.2f} s) and {rows_i} item rows ({nnz_i} entries, "
                    f"{ti:.2f} s) of the same matrix, f={f}; scaled by stored entries to one iteration"),
     }

@@ -283,35 +283,49 @@ __device__ void cg_solve_block(const float* A, const float* b, float* vec, float
 // run by all NTHR threads of the workgroup (every thread must call it): A x = b by a Cholesky factorisation
 // A = L L^T, x written to global memory.  The warm start plays no part.
 //   A     LDS, row stride F + 1 (so that a column is as free of bank conflicts as a row), lower triangle read
-//   col   LDS scratch of 2 (F + 4) floats, 16-byte aligned;  dinv: LDS scratch of F floats
+//   pan   LDS scratch of 2 * 4 * (F + 4) floats, 16-byte aligned (it may overlay b: b is in registers by then)
 // The lower triangle is cut into 4 x 4 blocks that live in registers, one or a few per thread; b rides along as one
 // more row of the matrix (row F: after the factorisation it holds z = L^-1 b, so the forward substitution costs
-// nothing).  Right-looking, one workgroup barrier per column: the owners of block column j / 4 publish column j as
-// it stands after the updates of columns < j; after the barrier every thread scales the entries it needs by
-// 1 / sqrt(a_jj) itself and updates its blocks a_ik -= l_ij l_kj.  Two column buffers alternate, so a thread that
-// is one column ahead never overwrites what a slower one still reads.  The back substitution L^T x = z runs on
-// wavefront 0 from L in LDS, one column per step.  A pivot that is not positive (A not positive definite, possible
-// only with confidences below 1) yields NaN in that row; LAPACK's LU fallback is not reproduced.
+// nothing).  Right-looking by block columns, one workgroup barrier per block column: the owners of block column c
+// publish their blocks as they stand after the updates of the columns before (a panel of F + 4 rows x 4); after
+// the barrier every thread factors the panel's 4 x 4 diagonal block itself (a few dozen operations, cheaper than
+// a second barrier), turns the panel rows of its block row and block column into rows of L by a 4 x 4 triangular
+// solve, and takes their product off its blocks.  Two panel buffers alternate, so a thread that is one block
+// column ahead never overwrites what a slower one still reads.  Blocks are numbered block column by block column,
+// so the threads of a wavefront own neighbouring block columns and the whole wavefront falls idle once the
+// factorisation has passed them.  The back substitution L^T x = z runs on wavefront 0 from L in LDS, one column
+// per step.  A pivot that is not positive (A not positive definite, possible only with confidences below 1)
+// yields NaN in that row; LAPACK's LU fallback is not reproduced.
+__device__ __forceinline__ float chol_rsqrt(float d) {
+    // 1 / sqrt(d): the hardware estimate and one Newton step (zero or negative d: not a number)
+    float inv = __builtin_amdgcn_rsqf(d);
+    return inv * fmaf(-0.5f * d * inv, inv, 1.5f);
+}
+
+// Row r of a panel block times the inverse transpose of the factored diagonal block: x L_D^T = r.
+__device__ __forceinline__ void chol_trsm_row(const float4 r, const float (&l)[6], const float (&iv)[4], float (&x)[4]) {
+    x[0] = r.x * iv[0];
+    x[1] = fmaf(-x[0], l[0], r.y) * iv[1];
+    x[2] = fmaf(-x[1], l[2], fmaf(-x[0], l[1], r.z)) * iv[2];
+    x[3] = fmaf(-x[2], l[5], fmaf(-x[1], l[4], fmaf(-x[0], l[3], r.w))) * iv[3];
+}
+
 template <int F, int NTHR>
-__device__ void chol_solve_block(float* A, const float* b, float* col, float* dinv, float* xg, int tid) {
+__device__ void chol_solve_block(float* A, const float* b, float* pan, float* xg, int tid) {
     constexpr int LDA = F + 1;
     constexpr int NBLK = F / 4;
-    constexpr int NTRI = NBLK * (NBLK + 1) / 2;
-    constexpr int NB = NTRI + NBLK;               // + the blocks of the row that carries b
-    constexpr int NBK = (NB + NTHR - 1) / NTHR;   // blocks per thread
-    constexpr int CB = F + 4;                     // floats of one column buffer
+    constexpr int NB = NBLK * (NBLK + 1) / 2 + NBLK;  // lower-triangle blocks + those of the row that carries b
+    constexpr int NBK = (NB + NTHR - 1) / NTHR;       // blocks per thread
+    constexpr int PB = 4 * (F + 4);                   // floats of one panel buffer
     float a[NBK][4][4];
     int bi[NBK], bj[NBK];  // block row / block column; bi == NBLK: the b row; bj == -1: no block
-    // Blocks are numbered column by column (block column c holds rows c .. NBLK, the last being b's), so that the
-    // threads of a wavefront own neighbouring block columns and the whole wavefront falls idle once the
-    // factorisation has passed them: the work of a column shrinks with the trailing matrix.
 #pragma unroll
     for (int s = 0; s < NBK; ++s) {
         const int id = tid + s * NTHR;
         bi[s] = 0;
         bj[s] = -1;
         if (id < NB) {
-            // first id of block column c: c (NBLK + 1) - c (c - 1) / 2
+            // first id of block column c: c (NBLK + 1) - c (c - 1) / 2  (rows c .. NBLK)
             const float h = (float)NBLK + 1.5f;
             int c = (int)(h - sqrtf(h * h - 2.f * (float)id));
             c = c < 0 ? 0 : (c > NBLK - 1 ? NBLK - 1 : c);
@@ -332,46 +346,77 @@ __device__ void chol_solve_block(float* A, const float* b, float* col, float* di
                 a[s][r][c] = v;
             }
     }
+    __syncthreads();  // b is in registers: the panel buffers may overlay it
     for (int cj = 0; cj < NBLK; ++cj) {
+        float* pb = pan + (cj & 1) * PB;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * cj + jj;
-            float* cb = col + (jj & 1) * CB;
+        for (int s = 0; s < NBK; ++s)
+            if (bj[s] == cj) {
 #pragma unroll
-            for (int s = 0; s < NBK; ++s)
-                if (bj[s] == cj)
-                    *reinterpret_cast<float4*>(cb + 4 * bi[s]) = make_float4(a[s][0][jj], a[s][1][jj], a[s][2][jj], a[s][3][jj]);
-            __syncthreads();
-            // 1 / sqrt(a_jj): the hardware estimate and one Newton step (a non-positive pivot gives NaN)
-            const float dj = cb[j];
-            float inv = __builtin_amdgcn_rsqf(dj);
-            inv = inv * fmaf(-0.5f * dj * inv, inv, 1.5f);
-            if (tid == 0) dinv[j] = inv;
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<float4*>(pb + 16 * bi[s] + 4 * r) = make_float4(a[s][r][0], a[s][r][1], a[s][r][2], a[s][r][3]);
+            }
+        __syncthreads();
+        bool any = false;
 #pragma unroll
-            for (int s = 0; s < NBK; ++s) {
-                if (bj[s] < cj) continue;
-                const float4 ri = *reinterpret_cast<const float4*>(cb + 4 * bi[s]);
-                const float4 rk = *reinterpret_cast<const float4*>(cb + 4 * bj[s]);
-                const float li[4] = {ri.x * inv, ri.y * inv, ri.z * inv, ri.w * inv};
-                const float lk[4] = {rk.x * inv, rk.y * inv, rk.z * inv, rk.w * inv};
-                if (bj[s] == cj) {
+        for (int s = 0; s < NBK; ++s) any = any || bj[s] >= cj;
+        if (!any) continue;
+        // the diagonal block D = L_D L_D^T: l = (l10, l20, l21, l30, l31, l32), iv = 1 / diagonal of L_D
+        float l[6], iv[4];
+        {
+            const float4 d0 = *reinterpret_cast<const float4*>(pb + 16 * cj);
+            const float4 d1 = *reinterpret_cast<const float4*>(pb + 16 * cj + 4);
+            const float4 d2 = *reinterpret_cast<const float4*>(pb + 16 * cj + 8);
+            const float4 d3 = *reinterpret_cast<const float4*>(pb + 16 * cj + 12);
+            iv[0] = chol_rsqrt(d0.x);
+            l[0] = d1.x * iv[0];
+            l[1] = d2.x * iv[0];
+            l[3] = d3.x * iv[0];
+            iv[1] = chol_rsqrt(fmaf(-l[0], l[0], d1.y));
+            l[2] = fmaf(-l[1], l[0], d2.y) * iv[1];
+            l[4] = fmaf(-l[3], l[0], d3.y) * iv[1];
+            iv[2] = chol_rsqrt(fmaf(-l[2], l[2], fmaf(-l[1], l[1], d2.z)));
+            l[5] = fmaf(-l[4], l[2], fmaf(-l[3], l[1], d3.z)) * iv[2];
+            iv[3] = chol_rsqrt(fmaf(-l[5], l[5], fmaf(-l[4], l[4], fmaf(-l[3], l[3], d3.w))));
+        }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+        for (int s = 0; s < NBK; ++s) {
+            if (bj[s] < cj) continue;
+            if (bj[s] == cj && bi[s] == cj) {
+                // the diagonal block itself becomes L_D (what lies above its diagonal is never read)
+                a[s][0][0] = 1.0f / iv[0];
+                a[s][1][0] = l[0]; a[s][1][1] = 1.0f / iv[1];
+                a[s][2][0] = l[1]; a[s][2][1] = l[2]; a[s][2][2] = 1.0f / iv[2];
+                a[s][3][0] = l[3]; a[s][3][1] = l[4]; a[s][3][2] = l[5]; a[s][3][3] = 1.0f / iv[3];
+                continue;
+            }
+            float pi[4][4];
 #pragma unroll
-                        for (int c = jj + 1; c < 4; ++c) a[s][r][c] = fmaf(-li[r], lk[c], a[s][r][c]);
-                        a[s][r][jj] = li[r];
-                    }
-                } else {
+            for (int r = 0; r < 4; ++r)
+                chol_trsm_row(*reinterpret_cast<const float4*>(pb + 16 * bi[s] + 4 * r), l, iv, pi[r]);
+            if (bj[s] == cj) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) a[s][r][c] = fmaf(-li[r], lk[c], a[s][r][c]);
-                }
+                    for (int c = 0; c < 4; ++c) a[s][r][c] = pi[r][c];
+                continue;
+            }
+            // one row of L of the block column's rows at a time (four registers live instead of sixteen)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float pk[4];
+                chol_trsm_row(*reinterpret_cast<const float4*>(pb + 16 * bj[s] + 4 * c), l, iv, pk);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[s][r][c] = fmaf(-pi[r][m], pk[m], a[s][r][c]);
             }
         }
     }
-    // L (rows below the diagonal are what the back substitution reads) and z to LDS
-    __syncthreads();  // the last column buffer is read by all before z overwrites buffer 0
+    // L (the rows below the diagonal are what the back substitution reads), z and 1 / diagonal to LDS
+    __syncthreads();  // the last panel is read by all before z and the inverses overwrite the buffers
+    float* zv = pan;
+    float* dinv = pan + PB;
 #pragma unroll
     for (int s = 0; s < NBK; ++s) {
         if (bj[s] < 0) continue;
@@ -380,8 +425,12 @@ __device__ void chol_solve_block(float* A, const float* b, float* col, float* di
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) A[(4 * bi[s] + r) * LDA + 4 * bj[s] + c] = a[s][r][c];
+            if (bi[s] == bj[s]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dinv[4 * bi[s] + r] = 1.0f / a[s][r][r];
+            }
         } else {
-            *reinterpret_cast<float4*>(col + 4 * bj[s]) = make_float4(a[s][0][0], a[s][0][1], a[s][0][2], a[s][0][3]);
+            *reinterpret_cast<float4*>(zv + 4 * bj[s]) = make_float4(a[s][0][0], a[s][0][1], a[s][0][2], a[s][0][3]);
         }
     }
     __syncthreads();
@@ -390,7 +439,7 @@ __device__ void chol_solve_block(float* A, const float* b, float* col, float* di
         const int lane = tid;
         float z[NC];
 #pragma unroll
-        for (int m = 0; m < NC; ++m) z[m] = (lane + 64 * m < F) ? col[lane + 64 * m] : 0.f;
+        for (int m = 0; m < NC; ++m) z[m] = (lane + 64 * m < F) ? zv[lane + 64 * m] : 0.f;
         for (int i = F - 1; i >= 0; --i) {
             float zi = z[0];
 #pragma unroll
@@ -399,8 +448,8 @@ __device__ void chol_solve_block(float* A, const float* b, float* col, float* di
 #pragma unroll
             for (int m = 0; m < NC; ++m) {
                 const int jc = lane + 64 * m;
-                const float l = A[i * LDA + (jc < F ? jc : F - 1)];
-                z[m] = jc < i ? fmaf(-l, xi, z[m]) : (jc == i ? xi : z[m]);
+                const float lv = A[i * LDA + (jc < F ? jc : F - 1)];
+                z[m] = jc < i ? fmaf(-lv, xi, z[m]) : (jc == i ? xi : z[m]);
             }
         }
 #pragma unroll
@@ -465,6 +514,11 @@ struct GramCfg {
     static constexpr int CGP = VEC + F;  // partial products of the block CG: one vector per wave + a control word
     static constexpr int FLOATS = CGP + 2 * NT * F + 4;
     static constexpr size_t BYTES = (size_t)FLOATS * 4;
+    // The exact solver's two panel buffers (2 * 4 * (F + 4) floats) overlay everything from the b partials on
+    // -- all of it dead once b is in registers -- or, at F = 32, the part of the tile area that A leaves free.
+    static constexpr int CHOL_PANEL = (FLOATS - BRED >= 8 * (F + 4)) ? BRED : F * LDX;
+    static_assert(CHOL_PANEL % 4 == 0 && CHOL_PANEL + 8 * (F + 4) <= (CHOL_PANEL == BRED ? FLOATS : BIGN),
+                  "no room for the panels of the exact solver");
     // first tile id of band-row b in the row-major enumeration of the upper triangle
     static constexpr int row_start(int b) { return b * NB - b * (b - 1) / 2; }
 };
@@ -756,9 +810,9 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
 
 // Consumer wave W: accumulates its tiles over the chunk, then stores them (executes the same barriers as the
 // producers).
-template <int NT, int W>
+template <int NT, int W, int lda>
 __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int ntiles, float* smem, bool single,
-                                              float* P, int lane, float unscale, int lda) {
+                                              float* P, int lane, float unscale) {
     using C = GramCfg<NT>;
     using WA = WaveAcc<NT, W>;
     constexpr int F = C::F;
@@ -833,7 +887,9 @@ __device__ __forceinline__ int64_t chunk_len(int64_t n, int nch) {
     return (per + TR - 1) / TR * TR;
 }
 
-template <int NT, bool BIG>
+// EXACT: the instantiation that ends a row with the Cholesky solve instead of conjugate gradients (cg_steps is
+// then ignored); kept apart so that the registers and the LDS stride of the iterative kernel stay what they are.
+template <int NT, bool BIG, bool EXACT>
 __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G,
@@ -893,16 +949,15 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
         sc = gram_scale(gmax, conf_max > 0.f ? conf_max : *conf_max_dev);
     }
     const float scale2 = sc[0] * sc[0], unscale = sc[1];
-    const bool exact = cg_steps < 0;          // Cholesky instead of conjugate gradients
-    const int lda = exact ? C::LDX : F;
+    constexpr int lda = EXACT ? C::LDX : F;
 
     switch (w) {
-        case 0: gram_consumer<NT, 0>(G, ntiles, smem, single, P, lane, unscale, lda); break;
-        case 1: if constexpr (NT > 1) gram_consumer<NT, 1>(G, ntiles, smem, single, P, lane, unscale, lda); break;
-        case 2: if constexpr (NT > 2) gram_consumer<NT, 2>(G, ntiles, smem, single, P, lane, unscale, lda); break;
-        case 3: if constexpr (NT > 3) gram_consumer<NT, 3>(G, ntiles, smem, single, P, lane, unscale, lda); break;
-        case 4: if constexpr (NT > 4) gram_consumer<NT, 4>(G, ntiles, smem, single, P, lane, unscale, lda); break;
-        case 5: if constexpr (NT > 5) gram_consumer<NT, 5>(G, ntiles, smem, single, P, lane, unscale, lda); break;
+        case 0: gram_consumer<NT, 0, lda>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 1: if constexpr (NT > 1) gram_consumer<NT, 1, lda>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 2: if constexpr (NT > 2) gram_consumer<NT, 2, lda>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 3: if constexpr (NT > 3) gram_consumer<NT, 3, lda>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 4: if constexpr (NT > 4) gram_consumer<NT, 4, lda>(G, ntiles, smem, single, P, lane, unscale); break;
+        case 5: if constexpr (NT > 5) gram_consumer<NT, 5, lda>(G, ntiles, smem, single, P, lane, unscale); break;
     }
     if (w >= NT) gram_producer<NT, BIG>(indices, data, Y, ks, ke, smem, tid - 64 * NT, scale2);
     __syncthreads();  // A (or the partial slot) and the b partials of the four entry groups are written
@@ -914,7 +969,7 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     }
     if (single) {
         __syncthreads();
-        if (exact) chol_solve_block<F, NTHR>(big, bvec, bred, vec, xrow, tid);
+        if constexpr (EXACT) chol_solve_block<F, NTHR>(big, bvec, smem + C::CHOL_PANEL, xrow, tid);
         else cg_solve_block<F, 2 * NT>(big, bvec, vec, smem + C::CGP, xrow, cg_steps, tid);
     }
 #ifdef MIREC_DEBUG_TIMING
@@ -927,7 +982,7 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
 }
 
 // Split rows: sum the chunk partials in chunk order, add G, mirror the upper triangle, solve.
-template <int NT>
+template <int NT, bool EXACT>
 __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
     int64_t row_begin, float* X, const float* __restrict__ G, const int32_t* __restrict__ chunk_ptr,
     const int32_t* __restrict__ mslot_ptr, const int32_t* __restrict__ multi_row, int cg_steps,
@@ -941,8 +996,7 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
     float* vec = smem + C::VEC;
 
     const int tid = threadIdx.x;
-    const bool exact = cg_steps < 0;
-    const int lda = exact ? C::LDX : F;
+    constexpr int lda = EXACT ? C::LDX : F;
     const int r = multi_row[blockIdx.x];
     const int nch = chunk_ptr[r + 1] - chunk_ptr[r];
     const float* P = partials + (size_t)mslot_ptr[r] * C::PART_STRIDE;
@@ -982,7 +1036,7 @@ __global__ __launch_bounds__(64 * NT) void als_finalize_kernel(
         }
     }
     __syncthreads();
-    if (exact) chol_solve_block<F, C::NTHR>(big, bvec, smem + C::BRED, vec, X + (row_begin + r) * F, tid);
+    if constexpr (EXACT) chol_solve_block<F, C::NTHR>(big, bvec, smem + C::CHOL_PANEL, X + (row_begin + r) * F, tid);
     else cg_solve_block<F, NT>(big, bvec, vec, smem + C::CGP, X + (row_begin + r) * F, cg_steps, tid);
 }
 
@@ -1011,11 +1065,11 @@ __global__ __launch_bounds__(256) void conf_absmax_kernel(const float* __restric
     }
 }
 
-template <int NT>
-static int launch_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
-                        float* X, const float* Y, const float* G, int cg_steps, const char* plan,
-                        const PlanLayout& L, int32_t chunk_nnz, const int64_t counts[3], float* partials,
-                        int64_t y_rows, float conf_max, const float* conf_max_dev, hipStream_t stream) {
+template <int NT, bool EXACT>
+static int launch_sweep_kind(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
+                             float* X, const float* Y, const float* G, int cg_steps, const char* plan,
+                             const PlanLayout& L, const int64_t counts[3], float* partials, int64_t y_rows,
+                             float conf_max, const float* conf_max_dev, hipStream_t stream) {
     using S = GramCfg<NT>;
     const int32_t* chunk_ptr = (const int32_t*)(plan + L.chunk_ptr);
     const int32_t* mslot_ptr = (const int32_t*)(plan + L.mslot_ptr);
@@ -1025,11 +1079,11 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
     bool* attr_done = once.slot();
     MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
     if (!*attr_done) {
-        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, false>,
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, false, EXACT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
-        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, true>,
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_gram_cg_kernel<NT, true, EXACT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
-        MIREC_HIP(hipFuncSetAttribute((const void*)als_finalize_kernel<NT>,
+        MIREC_HIP(hipFuncSetAttribute((const void*)als_finalize_kernel<NT, EXACT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES));
         *attr_done = true;
     }
@@ -1037,21 +1091,34 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
         // byte offsets into the gathered table are kept in 32 bits while the whole table is addressable that way
         const bool big = y_rows <= 0 || (uint64_t)y_rows * (uint64_t)(S::F * 4) > (1ull << 32);
         if (big)
-            hipLaunchKernelGGL((als_gram_cg_kernel<NT, true>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
+            hipLaunchKernelGGL((als_gram_cg_kernel<NT, true, EXACT>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
                                cg_steps, partials, conf_max, conf_max_dev);
         else
-            hipLaunchKernelGGL((als_gram_cg_kernel<NT, false>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
+            hipLaunchKernelGGL((als_gram_cg_kernel<NT, false, EXACT>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
                                cg_steps, partials, conf_max, conf_max_dev);
         MIREC_LAUNCH_CHECK();
     }
     if (counts[1] > 0) {
-        hipLaunchKernelGGL(als_finalize_kernel<NT>, dim3((unsigned)counts[1]), dim3(64 * NT), S::BYTES, stream,
+        hipLaunchKernelGGL((als_finalize_kernel<NT, EXACT>), dim3((unsigned)counts[1]), dim3(64 * NT), S::BYTES, stream,
                            row_begin, X, G, chunk_ptr, mslot_ptr, multi_row, cg_steps, partials);
         MIREC_LAUNCH_CHECK();
     }
     return MIREC_OK;
+}
+
+template <int NT>
+static int launch_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
+                        float* X, const float* Y, const float* G, int cg_steps, const char* plan,
+                        const PlanLayout& L, int32_t chunk_nnz, const int64_t counts[3], float* partials,
+                        int64_t y_rows, float conf_max, const float* conf_max_dev, hipStream_t stream) {
+    (void)chunk_nnz;
+    if (cg_steps < 0)
+        return launch_sweep_kind<NT, true>(indptr, indices, data, row_begin, X, Y, G, cg_steps, plan, L, counts,
+                                           partials, y_rows, conf_max, conf_max_dev, stream);
+    return launch_sweep_kind<NT, false>(indptr, indices, data, row_begin, X, Y, G, cg_steps, plan, L, counts, partials,
+                                        y_rows, conf_max, conf_max_dev, stream);
 }
 
 }  // namespace mirec

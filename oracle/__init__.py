@@ -28,5 +28,6 @@ from .oracle import (  # noqa: F401
     num_threads,
     scores,
     set_num_threads,
+    use_widest_build,
     topk,
 )

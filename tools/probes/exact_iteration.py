@@ -43,6 +43,9 @@ def run(cg_steps, short_max, iters=3):
 
 t_cg, ms_cg, _, _ = run(3, None)
 print("CG-3   : %.2f ms per iteration  %s" % (t_cg * 1e3, {k: round(v, 2) for k, v in ms_cg.items()}), flush=True)
+t_g, ms_g, _, _ = run(3, 0)
+print("CG-3, every row through the explicit-Gram kernel: %.2f ms per iteration  %s" %
+      (t_g * 1e3, {k: round(v, 2) for k, v in ms_g.items()}), flush=True)
 t_ex, ms_ex, X, Y = run(-1, 0)
 print("exact  : %.2f ms per iteration  %s" % (t_ex * 1e3, {k: round(v, 2) for k, v in ms_ex.items()}), flush=True)
 
