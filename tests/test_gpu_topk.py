@@ -387,6 +387,10 @@ def test_randomised_parity_fixed_seed(dev):
     print(f"rounding-sensitive cases {len(fz.SENSITIVE)}, low-rank outlier cases {len(fz.DEGENERATE)} "
           f"(worst A-norm ratio {max((t[4] for t in fz.DEGENERATE), default=0.0):.2f})")
     assert len(fz.DEGENERATE) <= MAX_LOW_RANK_OUTLIERS and len(fz.SENSITIVE) <= MAX_SENSITIVE
+    # the exact (Cholesky) half-sweep: backward error of every row against LAPACK's fp32 posv on the same system
+    for i in range(120):
+        ok, desc = fz.case_exact(np.random.default_rng([13, i]))
+        assert ok, f"exact half-sweep case {i}: {desc}"
 
 
 @pytest.mark.timeout(600)
