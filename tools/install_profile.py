@@ -2,8 +2,9 @@
 
 usage: python tools/install_profile.py <tag> <previous tag> "<one-line description of the capture>"
 Writes profiles/<tag>_bench_kernel_stats.{md,csv}, _bench_line.json, _pmc_traffic.json; carries the notes below
-the table and the L2 counter file over from the previous tag, removes the previous tag's files and renames the
-references to them in the design notes at the repository root.
+the table over from the previous tag, removes the previous tag's files (but for the L2 and SQ counter files,
+which keep the tag of their own capture) and renames the references to them in the design notes at the
+repository root.
 """
 import csv
 import glob
@@ -42,10 +43,14 @@ open(os.path.join(prof, f"{tag}_bench_kernel_stats.md"), "w").write(out)
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
 open(os.path.join(prof, f"{tag}_bench_line.json"), "w").write(json.dumps(d) + "\n")
 shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(prof, f"{tag}_pmc_traffic.json"))
-shutil.move(os.path.join(prof, f"{prev}_l2_hit_rates.json"), os.path.join(prof, f"{tag}_l2_hit_rates.json"))
+# counter files that no capture of this script renews stay under the tag of the capture they were taken with
+keep = ("_l2_hit_rates.json", "_sq_counters.json")
 for f in glob.glob(os.path.join(prof, f"{prev}_*")):
-    os.remove(f)
+    if not f.endswith(keep):
+        os.remove(f)
 p = os.path.join(root, "DESIGN.md")
 text = open(p).read()   # (read before the file is opened for writing)
-open(p, "w").write(text.replace(prev + "_", tag + "_"))
+for k in keep:
+    text = text.replace(prev + k, "\0KEEP" + k)
+open(p, "w").write(text.replace(prev + "_", tag + "_").replace("\0KEEP", prev))
 print(out[:1800])
