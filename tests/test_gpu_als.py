@@ -262,6 +262,39 @@ def test_fit_zipf_case_and_ranking_metrics(dev, golden_dir):
         assert abs(mg[key] - mo[key]) < 3e-3, (key, mg, mo)
 
 
+def test_fit_zipf_case_at_5000_by_1000(dev):
+    """The same known-answer case at 5 000 x 1 000 with ~50 entries per user (f=64, 15 iterations, alpha 40,
+    reg 0.01), against the oracle run here: factors, held-out ranking metrics and how many of the 100 000
+    top-20 ids agree (factors 2e-3 apart exchange neighbours around rank 20; equal factors give equal ids, which
+    the top-K tests check bit for bit)."""
+    from movie_recommender_system_amd import AlternatingLeastSquares, synth
+    from oracle import als_numpy
+    full = synth.interactions(47, 5000, 1000, 50.0)
+    train, held = synth.split_holdout(full, 48, 0.2)
+    model = AlternatingLeastSquares(factors=64, iterations=15, regularization=0.01, alpha=40, random_state=42)
+    model.fit(train)
+    Xo, Yo = oracle.als_fit(train, factors=64, regularization=0.01, alpha=40, iterations=15, random_state=42)
+    eu, ei = rel(model.user_factors, Xo), rel(model.item_factors, Yo)
+    ids, _ = model.recommend_all(train, N=20)
+    oid, _ = oracle.topk(Xo, Yo, 20, liked=train)
+    same = float(np.mean([len(set(a) & set(b)) for a, b in zip(ids, oid)])) / 20.0
+    mg = als_numpy.ranking_metrics(ids, held, 20)
+    mo = als_numpy.ranking_metrics(oid, held, 20)
+    print(f"5000 x 1000: users {eu:.2e}, items {ei:.2e} from the oracle; top-20 overlap {same:.4f}; "
+          f"metrics device {mg} oracle {mo}")
+    # measured: 1.6e-3 / 1.6e-3, overlap 0.998, precision / recall / F1 within 5e-5, hit rate within 7e-4
+    assert eu < 5e-3 and ei < 5e-3
+    assert same > 0.995
+    for key in ("precision", "recall", "f1", "hit_rate"):
+        assert abs(mg[key] - mo[key]) < 1.5e-3, (key, mg, mo)
+    # the device's own top-20 of the ORACLE's factors is the oracle's, id for id
+    import torch
+    from movie_recommender_system_amd import engine as E
+    W = E.scoring_width(64, 20)
+    dids, _ = E.topk(E.pad_factors(Xo, W, dev), E.pad_factors(Yo, W, dev), 20, E.DeviceCSR.from_scipy(train, dev))
+    assert np.array_equal(dids.cpu().numpy(), oid)
+
+
 def test_alpha_applied_once_or_prescaled(dev):
     """als/als.py:171,174 scales the matrix AND passes alpha (confidence
     alpha^2); als_recommender.py:132,136 passes alpha only.  Both reproduce."""
