@@ -1,0 +1,60 @@
+"""Does the order of the item sweep matter to the top-K pass?  Trains the benchmark's factors for a few iterations,
+then times the all-users top-20 with the items in their own order and in the order of descending norm (the liked
+rows are renumbered and re-sorted to match): with the largest scores met first the thresholds rise early and fewer
+candidates are appended.  Checks that both orders name the same items.
+
+usage: topk_item_order.py [iterations]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from movie_recommender_system_amd import engine as E, synth  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+dev = torch.device("cuda", 0)
+U, I, f = 1_000_000, 27_000, 128
+indptr, indices, data = synth.interactions_torch(42, U, I, 50.0, dev)
+Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
+rs = np.random.RandomState(42)
+X = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, f, dev)
+Y = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, f, dev)
+eng = E.AlsEngine(Cui, None, X, Y, 0.01, 3)
+for _ in range(iters):
+    eng.iteration()
+torch.cuda.synchronize()
+norms = Y.norm(dim=1)
+print("item norms after %d iterations: min %.3g  median %.3g  max %.3g" % (
+    iters, norms.min().item(), norms.median().item(), norms.max().item()), flush=True)
+
+
+def timed(Yt, mask, tag):
+    ids, sc = E.topk(X, Yt, 20, mask)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ids, sc = E.topk(X, Yt, 20, mask)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    print("%-28s %.2f ms" % (tag, min(ts)), flush=True)
+    return ids, sc
+
+
+ids0, sc0 = timed(Y, Cui, "items in their own order")
+order = torch.argsort(norms, descending=True, stable=True)          # new position -> item
+pos = torch.empty_like(order)
+pos[order] = torch.arange(I, device=dev)                            # item -> new position
+rows = torch.repeat_interleave(torch.arange(U, device=dev), indptr[1:] - indptr[:-1])
+key = rows * I + pos[indices.long()]
+key, _ = torch.sort(key)
+mask = E.DeviceCSR(indptr, (key % I).to(torch.int32), data, (U, I))
+ids1, sc1 = timed(Y[order].contiguous(), mask, "items by descending norm")
+back = order[ids1.long().clamp(min=0)].to(torch.int32)
+same_sets = bool((torch.sort(back, dim=1).values == torch.sort(ids0, dim=1).values).all())
+print("same items named:", same_sets, " same scores:", bool((torch.sort(sc1, dim=1).values == torch.sort(sc0, dim=1).values).all()))
