@@ -417,6 +417,26 @@ def test_full_size_als_and_lightfm_top20_on_sampled_users(dev):
     oid, osc = oracle.topk(Q[pick], Y, 20, liked=sub)
     t = torch.from_numpy(pick).to(dev)
     assert np.array_equal(ids[t].cpu().numpy(), oid) and np.array_equal(sc[t].cpu().numpy(), osc)
+    # properties that hold for every one of the 1 M users, checked on all of them: best first with ties by
+    # ascending item, no item twice, every id valid, no liked item, and every score the fp32 chain of its pair
+    # (re-computed here for a stride of the users)
+    assert bool(((sc[:, :-1] > sc[:, 1:]) | ((sc[:, :-1] == sc[:, 1:]) & (ids[:, :-1] < ids[:, 1:]))).all())
+    assert bool((ids >= 0).all()) and bool((ids < I).all())
+    assert bool((torch.sort(ids, dim=1).values.diff(dim=1) > 0).all())
+    rows = torch.repeat_interleave(torch.arange(U, device=dev), indptr[1:] - indptr[:-1])
+    liked_keys = rows * I + indices.long()                       # ascending: rows ascending, columns ascending in a row
+    got_keys = (torch.arange(U, device=dev)[:, None] * I + ids.long()).reshape(-1)
+    at = torch.searchsorted(liked_keys, got_keys).clamp(max=liked_keys.numel() - 1)
+    assert not bool((liked_keys[at] == got_keys).any())
+    del rows, liked_keys, got_keys, at
+    stride = torch.arange(0, U, 97, device=dev)
+    chain = torch.zeros((stride.numel(), 20), dtype=torch.float32, device=dev)
+    ys = dY[ids[stride].long()]                                  # [n, 20, f]
+    for c in range(f):                                           # s = fma(q[c], y[c], s), ascending c
+        chain = torch.addcmul(chain, dQ[stride, c:c + 1], ys[:, :, c])
+    # (addcmul rounds the product before the sum where the kernel's chain is fused: equal to a few ulps, not bits)
+    assert float(((chain - sc[stride]).abs() / sc[stride].abs().clamp(min=1e-30)).max()) < 1e-5
+    del ys, chain
     # LightFM: the hybrid model's shape (identity + 3 tokens per user, identity + tags per item)
     p = synth.lightfm_problem(42, U, I)
     m = LightFMScorer(p["user_embeddings"], p["user_biases"], p["item_embeddings"], p["item_biases"])
@@ -425,3 +445,6 @@ def test_full_size_als_and_lightfm_top20_on_sampled_users(dev):
     ir = oracle.lightfm_repr(p["item_features"], p["item_embeddings"], p["item_biases"])
     oid, osc = oracle.lightfm_topk(ur, ir, 20)
     assert np.array_equal(lids[pick], oid) and np.array_equal(lsc[pick], osc)
+    # every user's list: best first, ties by ascending item, valid ids, no item twice
+    assert bool(((lsc[:, :-1] > lsc[:, 1:]) | ((lsc[:, :-1] == lsc[:, 1:]) & (lids[:, :-1] < lids[:, 1:]))).all())
+    assert lids.min() >= 0 and lids.max() < I and bool((np.diff(np.sort(lids, axis=1), axis=1) > 0).all())
