@@ -222,6 +222,8 @@ def main():
     for _ in range(args.warmup):
         drv.iteration()
     eng.events = []
+    if world > 1:
+        drv.events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -230,6 +232,8 @@ def main():
     elapsed = time.perf_counter() - t0
     times = eng.event_times_ms()
     eng.events = None
+    exchange = {k: v[0] / max(v[1], 1) for k, v in drv.exchange_times_ms().items()}
+    drv.events = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -316,6 +320,9 @@ def main():
              "user_short_rows": u_short, "item_short_rows": eng.plan_i.n_short_rows,
              "user_chunks": u_chunks, "item_chunks": eng.plan_i.n_chunks,
              "user_blocks": len(eng.user_blocks),
+             # N > 1: what this rank's compute stream spends per iteration waiting for the gathers of the user slabs
+             # that its solves did not hide, and on the item exchange
+             "exchange_ms_per_iteration": exchange,
              "item_split_rows": eng.plan_i.n_split_rows,
              # interaction-matrix storage on this rank (both orientations) against the whole matrix's
              "resident_matrix_bytes": eng.resident_matrix_bytes(),

@@ -298,10 +298,35 @@ class ShardedAlsDriver:
                 # async: the collective waits for the solve just enqueued and runs beside the next block's
                 pending.append(dist.all_gather_into_tensor(self.Xpad[s0:s1], self.Xpad[p0:p1], group=self.group,
                                                            async_op=True))
+        t0 = self._mark()
         for w in pending:
             w.wait()
+        t1 = self._mark()
         self.solve_items(self.item_bounds[r], self.item_bounds[r + 1])
+        t2 = self._mark()
         allgather_rows(self.Y, self.item_bounds, r, self.group, self._sy)
+        if t0 is not None:
+            self.events.append(("wait_user_exchange", t0, t1))
+            self.events.append(("item_exchange", t2, self._mark()))
+
+    # events = [] switches on the timing of what the compute stream spends on the exchanges (device tensors only):
+    # the wait for the user slabs' gathers that the solves did not hide, and the item exchange
+    events = None
+
+    def _mark(self):
+        if self.events is None or not self.Xpad.is_cuda:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def exchange_times_ms(self) -> dict:
+        """Sum and count of the recorded intervals per name (call after a synchronize)."""
+        out = {}
+        for name, a, b in self.events or []:
+            t, n = out.get(name, (0.0, 0))
+            out[name] = (t + a.elapsed_time(b), n + 1)
+        return out
 
 
 def gpu_driver(Cui, Ciu, X: torch.Tensor, Y: torch.Tensor, regularization: float, cg_steps: int, rank: int,
