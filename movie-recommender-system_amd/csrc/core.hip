@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace mirec
 
-extern "C" int mirec_version(void) { return 100; }
+extern "C" int mirec_version(void) { return 101; }  // 101: cg_steps = MIREC_SOLVE_EXACT
 
 extern "C" const char* mirec_last_error(void) { return mirec::g_error; }
 

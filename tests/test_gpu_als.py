@@ -320,11 +320,12 @@ def test_alpha_applied_once_or_prescaled(dev):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,users,items", [(3, 50, 7), (4, 1000, 3), (2, 60_000, 5_000)])
-def test_sharded_driver_with_shards_without_rows(dev, world, users, items):
+@pytest.mark.parametrize("world,users,items,exact", [(3, 50, 7, 0), (4, 1000, 3, 0), (2, 60_000, 5_000, 0),
+                                                     (2, 6_000, 500, 1)])
+def test_sharded_driver_with_shards_without_rows(dev, world, users, items, exact):
     """The sharded device driver on `world` ranks that share this one GPU (gloo, collectives staged through the
     host: tools/rehearse_check.py) where some ranks own no user block or no item at all: factors equal the
-    one-rank run bit for bit."""
+    one-rank run bit for bit.  The last case runs the exact (Cholesky) solver on both sides."""
     import os
     import socket
     import subprocess
@@ -334,7 +335,7 @@ def test_sharded_driver_with_shards_without_rows(dev, world, users, items):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, REHEARSE_USERS=str(users), REHEARSE_ITEMS=str(items))
+    env = dict(os.environ, REHEARSE_USERS=str(users), REHEARSE_ITEMS=str(items), REHEARSE_EXACT=str(exact))
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(root, "tools", "rehearse_check.py")], env=env, capture_output=True, text=True,

@@ -1,7 +1,7 @@
 """Two ranks on one GPU (gloo, host-staged collectives as in tools/rehearse_multi_rank.py): the factors after two
 sharded iterations must equal, bit for bit, those of a one-rank run of the same problem.  Launch with
 torch.distributed.run --nproc-per-node 2.  REHEARSE_USERS / REHEARSE_ITEMS override the problem size (small ones
-leave ranks and blocks without rows)."""
+leave ranks and blocks without rows); REHEARSE_EXACT=1 runs the exact (Cholesky) solver instead of the CG steps."""
 import os
 import sys
 
@@ -43,6 +43,8 @@ torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 U, I, f = int(os.environ.get("REHEARSE_USERS", 60_000)), int(os.environ.get("REHEARSE_ITEMS", 5_000)), 128
 rs = np.random.RandomState(7)
+EXACT = os.environ.get("REHEARSE_EXACT", "0") == "1"
+CG, SHORT_MAX = (-1, 0) if EXACT else (3, None)
 X0 = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, f, dev)
 Y0 = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, f, dev)
 
@@ -54,9 +56,9 @@ def run(r, w):
         ip, ix, dt = synth.interactions_torch(7, U, I, 40.0, dev, users=(a, b))
         shards.append((a, b, E.DeviceCSR(ip, ix, dt * 40.0, (b - a, I))))
     if w == 1:
-        drv, eng = D.gpu_driver(shards[0][2], None, X0.clone(), Y0.clone(), 0.01, 3, 0, 1)
+        drv, eng = D.gpu_driver(shards[0][2], None, X0.clone(), Y0.clone(), 0.01, CG, 0, 1, short_max=SHORT_MAX)
     else:
-        drv, eng = D.gpu_driver(shards, None, X0.clone(), Y0.clone(), 0.01, 3, r, w)
+        drv, eng = D.gpu_driver(shards, None, X0.clone(), Y0.clone(), 0.01, CG, r, w, short_max=SHORT_MAX)
     for _ in range(2):
         drv.iteration()
     torch.cuda.synchronize()
