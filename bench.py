@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--no-lightfm-train", action="store_true")
     ap.add_argument("--no-lightfm", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the factors=64 figures beside the headline")
+    ap.add_argument("--no-requests", action="store_true", help="skip the per-request latency figures")
     return ap.parse_args()
 
 
@@ -151,6 +152,112 @@ def cpu_side_baselines(Cu, items, f, k, seed, n_users=4000):
     return {"cores": oracle.num_threads(), "sample_users": n_users,
             "top20_users_per_s": n_users / t_top, "lightfm_top20_users_per_s": n_users / t_lfm,
             "lightfm_warp_examples_per_s_one_thread": coo.nnz / t_warp}
+
+
+def _percentiles(samples_s):
+    a = np.sort(np.asarray(samples_s)) * 1e6
+    return {"p50_us": float(a[len(a) // 2]), "p99_us": float(a[int(len(a) * 0.99)]), "mean_us": float(a.mean()),
+            "calls": int(len(a))}
+
+
+def request_latency(dev, X, Y, f, liked_dev, items, seed, calls=2000):
+    """The reference's real serve path, one user per request (recommenders/als_recommender.py:181-186 and :237
+    behind api.py:26-34; hybrid_docker/inference.py:156-165,197): wall time per call of the plugin's
+    `recommend_for_user(N=20)` and `get_similar_items`, and of `compute_recommendations`, with everything resident
+    on the device, against the same request answered on the host (the oracle's chain, and numpy's sgemv + partial
+    sort, which is what implicit's CPU path amounts to).  The reference's published figure for this call is
+    0.30 ms median / 0.37 ms mean at 11 557 items, f = 64 (notebooks/baseline_als.ipynb cell fd92678d)."""
+    import scipy.sparse as sp
+    import torch
+    import oracle
+    from movie_recommender_system_amd import ALSRecommender, AlternatingLeastSquares, LightFMScorer, artifacts, synth
+    from movie_recommender_system_amd.lightfm import compute_recommendations
+
+    out = {"reference_published": {"median_ms": 0.30, "mean_ms": 0.37, "items": 11557, "factors": 64,
+                                   "source": "notebooks/baseline_als.ipynb cell fd92678d"}}
+    rng = np.random.default_rng(seed)
+    n_users = min(200_000, X.shape[0])           # users the plugin serves here (every request names one of them)
+    M = _leading_rows(liked_dev, n_users)
+    M.data[:] = 1.0
+    pick = rng.integers(0, n_users, calls + 200)
+    for ff in sorted({64, f}):
+        model = AlternatingLeastSquares(factors=ff, device=dev)
+        if ff == f:
+            model.user_factors = X[:n_users, :f].contiguous().cpu().numpy()
+            model.item_factors = Y[:, :f].contiguous().cpu().numpy()
+        else:
+            model.user_factors = rng.standard_normal((n_users, ff)).astype(np.float32) * 0.1
+            model.item_factors = rng.standard_normal((items, ff)).astype(np.float32) * 0.1
+        rec = ALSRecommender({"artefacts": {}, "metadata": {}, "device": str(dev)}, "als@bench")
+        rec.model, rec.train_matrix = model, M
+        rec.user_mappings = {"user_to_idx": {str(u): u for u in range(n_users)}, "n_users": n_users}
+        rec.movie_mappings = {"idx_to_movie": {i: str(i) for i in range(items)},
+                              "movie_to_idx": {str(i): i for i in range(items)}, "n_movies": items}
+        rec.most_popular_movies = artifacts.popularity_order(M)
+        rec.is_loaded = True
+        rec.warmup()
+        ts, tsim = [], []
+        for j, u in enumerate(pick):
+            t0 = time.perf_counter()
+            res = rec.recommend_for_user(str(int(u)), N=20)
+            ts.append(time.perf_counter() - t0)
+            assert res.method == "ALS", rec.last_scoring_error
+        for j, u in enumerate(pick[:600]):
+            t0 = time.perf_counter()
+            rec.get_similar_items(str(int(u) % items), N=20)
+            tsim.append(time.perf_counter() - t0)
+        # the same request on the host: the oracle (1 thread does all the work of a single query) and numpy
+        # (two loops: the oracle's idle OpenMP threads spin for a while after a call and would sit on the
+        # cores numpy's BLAS threads want)
+        tor, tnp = [], []
+        Yh, Xh = model.item_factors, model.user_factors
+        for u in pick[:300]:
+            row = M[int(u)]
+            t0 = time.perf_counter()
+            sc = Yh @ Xh[u]
+            sc[row.indices] = -np.inf
+            top = np.argpartition(-sc, 20)[:20]
+            top = top[np.argsort(-sc[top])]
+            tnp.append(time.perf_counter() - t0)
+        for u in pick[:60]:
+            row = M[int(u)]
+            t0 = time.perf_counter()
+            oid, _ = oracle.topk(Xh[u:u + 1], Yh, 20, liked=row)
+            tor.append(time.perf_counter() - t0)
+        got = rec.recommend_for_user(str(int(pick[0])), N=20)
+        oid, _ = oracle.topk(Xh[pick[0]:pick[0] + 1], Yh, 20, liked=M[int(pick[0])])
+        assert [r["movie_id"] for r in got.recommendations] == [str(int(i)) for i in oid[0]]
+        out[f"als_f{ff}_{items}_items"] = {
+            "recommend_for_user": _percentiles(ts[200:]), "get_similar_items": _percentiles(tsim[100:]),
+            "cpu_oracle_one_thread": _percentiles(tor[5:]), "cpu_numpy_sgemv_argpartition": _percentiles(tnp[50:]),
+            "scoring_failures": rec.scoring_failures}
+        rec.teardown()
+        del rec, model
+    for ni in sorted({7208, items}):
+        nu = 20_000
+        prob = synth.lightfm_problem(44, nu, ni)
+        sc = LightFMScorer(prob["user_embeddings"], prob["user_biases"], prob["item_embeddings"], prob["item_biases"],
+                           device=dev)
+        state = {"model": sc, "user_features": prob["user_features"], "item_features": prob["item_features"],
+                 "inv_item_map": {i: i for i in range(ni)}, "user_to_idx": {u: u for u in range(nu)},
+                 "user_feature_mapping": {}}
+        ts = []
+        for u in pick[:1200]:
+            t0 = time.perf_counter()
+            compute_recommendations(int(u) % nu, state, top_k=20)
+            ts.append(time.perf_counter() - t0)
+        ur = oracle.lightfm_repr(prob["user_features"][:64], prob["user_embeddings"], prob["user_biases"])
+        ir = oracle.lightfm_repr(prob["item_features"], prob["item_embeddings"], prob["item_biases"])
+        tor = []
+        for u in range(40):
+            t0 = time.perf_counter()
+            oracle.lightfm_topk(ur[u:u + 1], ir, 20)
+            tor.append(time.perf_counter() - t0)
+        out[f"lightfm_nc15_{ni}_items"] = {"compute_recommendations": _percentiles(ts[200:]),
+                                           "cpu_oracle_scoring_only_one_thread": _percentiles(tor[5:])}
+        del sc, state, prob
+    torch.cuda.synchronize()
+    return out
 
 
 def main():
@@ -413,6 +520,8 @@ def main():
         cpu = cpu_baseline(Cu0, eng.Ciu_local, U, I, nnz, f, args.regularization, args.cpu_seconds, args.seed)
         extra["speedup_vs_cpu_baseline"] = cpu["value"] / s_per_iter
         extra["cpu_oracle_other_passes"] = cpu_side_baselines(Cu0, I, f, args.topk, args.seed)
+        if not args.no_requests:
+            extra["request_latency"] = request_latency(dev, X, Y, f, Cu0, I, args.seed)
         if f != 64 and not args.no_config1:
             # BASELINE configs[0]: the same matrix at factors = 64 -- the CPU oracle on a bounded sample and the
             # device iteration beside it (same shards and plans' policy, factor width 64)

@@ -187,6 +187,25 @@ int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, int f, co
                const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
                float* out_scores, void* ws, size_t ws_bytes, mirec_stream_t stream);
 
+/* The same contract for a handful of queries -- the reference's serving calls score ONE
+ * user (recommenders/als_recommender.py:181-186), one item (:237) or one user
+ * representation (hybrid_docker/inference.py:156-165,197) per request.  mirec_topk gives
+ * a workgroup 128 or 256 queries and walks it through all items, which leaves the chip idle
+ * below a few thousand queries; this entry point splits the items over the workgroups
+ * instead (256 per workgroup, each lane the fp32 chain of one item), ranks every tile's
+ * scores and merges the tiles' k best per query.  Arguments and result bits as mirec_topk
+ * (one difference: a NaN score is never listed, and -0 counts as +0), any f that is a
+ * multiple of 8.  ws (device memory, 16-byte aligned) must hold
+ * mirec_topk_small_workspace_bytes(nq, ni, k) = 8 * nq * k * ceil(ni / 256) bytes; its
+ * contents mean nothing before or after the call.  nq <= MIREC_TOPK_SMALL_MAX_QUERIES.
+ * Pointers may address rows inside larger resident arrays (Q = X + u * f,
+ * mask_indptr = indptr + u, q_norm = norms + u), so a request uploads nothing. */
+#define MIREC_TOPK_SMALL_MAX_QUERIES 65536
+size_t mirec_topk_small_workspace_bytes(int64_t nq, int64_t ni, int k);
+int mirec_topk_small(const float* Q, int64_t nq, const float* Y, int64_t ni, int f, const int64_t* mask_indptr,
+                     const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k,
+                     int32_t* out_ids, float* out_scores, void* ws, size_t ws_bytes, mirec_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * LightFM representations (lightfm `compute_representation`, reached from
  * `model.predict` at hybrid_docker/inference.py:159-165,188-194):

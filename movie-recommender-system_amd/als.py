@@ -46,6 +46,27 @@ def _hide_filtered(ids: torch.Tensor, scores: torch.Tensor, mask) -> torch.Tenso
     return torch.where(scores == _FILTERED, torch.full_like(ids, -1), ids)
 
 
+class _ServingState:
+    """Device-resident state behind the per-request calls: nothing here is uploaded again per request."""
+
+    def __init__(self, dev: torch.device, Y: torch.Tensor, X: torch.Tensor, norms: torch.Tensor):
+        self.dev, self.Y, self.X, self.norms = dev, Y, X, norms
+        self._bufs = {}
+
+    def buffers(self, N: int):
+        """(device int32[2N]: ids then score bits, its pinned host twin, the workspace of one query) for lists of
+        length N."""
+        b = self._bufs.get(N)
+        if b is None:
+            lib = _lib.require()
+            out = torch.empty(2 * N, dtype=torch.int32, device=self.dev)
+            host = torch.empty(2 * N, dtype=torch.int32).pin_memory()
+            ws = torch.empty(int(lib.mirec_topk_small_workspace_bytes(1, self.Y.shape[0], N)), dtype=torch.uint8,
+                             device=self.dev)
+            b = self._bufs[N] = (out, host, ws)
+        return b
+
+
 class AlternatingLeastSquares:
     """Implicit-feedback ALS (Hu, Koren, Volinsky) with the conjugate-gradient
     solver of Takacs, Pilaszy and Tikk: ``cg_steps`` (3) warm-started steps per
@@ -84,6 +105,8 @@ class AlternatingLeastSquares:
         self._lock = threading.Lock()
         self._dev_items = None       # padded item factors on the device (scoring width)
         self._item_norms = None
+        self._serving = None         # device-resident state of the per-request calls (_ServingState)
+        self._attached = None        # (host CSR, DeviceCSR) of attach_user_items
 
     def __getstate__(self):
         return {
@@ -142,6 +165,7 @@ class AlternatingLeastSquares:
             self.item_factors = Y[:, :self.factors].contiguous().cpu().numpy()
             self._dev_items = None
             self._item_norms = None
+            self._serving = None
 
     # -------------------------------------------------------------- inference
     def _device_items(self, dev: torch.device):
@@ -149,6 +173,85 @@ class AlternatingLeastSquares:
             W = E.scoring_width(self.factors, 1)
             self._dev_items = E.pad_factors(self.item_factors, W, dev)
         return self._dev_items
+
+    def attach_user_items(self, user_items) -> None:
+        """Keep the interaction matrix (one CSR row per user of the model) on the device, so that
+        ``recommend(userid, None, ...)`` filters a user's liked items without receiving, slicing or uploading a
+        row per request.  ``None`` detaches."""
+        if user_items is None:
+            self._attached = None
+            return
+        m = _check_csr(user_items)
+        if self.user_factors is not None and m.shape[0] != self.user_factors.shape[0]:
+            raise ValueError("attach_user_items needs one row per user of the model")
+        if not m.has_sorted_indices:
+            m = m.sorted_indices()
+        dev = E.require_cuda(self.device)
+        with self._lock, torch.cuda.device(dev):
+            self._attached = (m, E.DeviceCSR.from_scipy(m, dev))
+
+    def _serving_state(self, dev: torch.device) -> "_ServingState":
+        """Everything a request needs, resident: both factor matrices at the scoring width, the item norms,
+        and per-N output / workspace / pinned download buffers.  Call with the lock held."""
+        st = self._serving
+        if st is None or st.dev != dev:
+            Yd = self._device_items(dev)
+            st = _ServingState(dev, Yd, E.pad_factors(self.user_factors, Yd.shape[1], dev),
+                               torch.from_numpy(self.item_norms).to(dev))
+            self._serving = st
+        return st
+
+    def _one_request(self, q_ptr: int, N: int, mask_ptrs, norm_ptrs, dev: torch.device):
+        """One query row that already sits on the device -> (ids, scores) numpy arrays of length N.  Two kernel
+        launches and one 8N-byte download; nothing is uploaded or allocated once the buffers for this N exist."""
+        lib = _lib.require()
+        st = self._serving_state(dev)
+        out, host, ws = st.buffers(int(N))
+        ni, W = st.Y.shape
+        mi, mx = mask_ptrs if mask_ptrs is not None else (0, 0)
+        yn, qn = norm_ptrs if norm_ptrs is not None else (0, 0)
+        base = out.data_ptr()
+        _lib.check(lib.mirec_topk_small(q_ptr, 1, st.Y.data_ptr(), ni, W, mi, mx, yn, qn, int(N), base, base + 4 * N,
+                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "mirec_topk_small")
+        host.copy_(out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        arr = host.numpy()
+        ids = arr[:N].copy()
+        scores = arr[N:].view(np.float32).copy()
+        return ids, scores
+
+    def _recommend_one(self, uid: int, user_items, N: int, filter_liked: bool):
+        """The serving call of the reference, ``model.recommend(user_idx, train_matrix[user_idx], N=N,
+        filter_already_liked_items=True)`` (recommenders/als_recommender.py:181-186): one resident user row
+        against all items."""
+        if not 0 <= uid < self.user_factors.shape[0]:
+            raise IndexError(f"userid {uid} is out of range")
+        dev = E.require_cuda(self.device)
+        with self._lock, torch.cuda.device(dev):
+            st = self._serving_state(dev)
+            keep = None
+            mask_ptrs = None
+            if filter_liked:
+                if user_items is None:
+                    if self._attached is None:
+                        raise ValueError("user_items is needed to filter liked items (or attach_user_items first)")
+                    d = self._attached[1]
+                    mask_ptrs = (d.indptr.data_ptr() + 8 * uid, d.indices.data_ptr())
+                else:
+                    if not sp.isspmatrix_csr(user_items):
+                        raise ValueError("user_items needs to be a CSR sparse matrix")
+                    if user_items.shape[0] != 1:
+                        raise ValueError("user_items must contain 1 row for every user in userids")
+                    idx = np.sort(user_items.indices[user_items.indptr[0]:user_items.indptr[1]]).astype(np.int32)
+                    keep = (torch.from_numpy(idx).to(dev) if idx.size else torch.zeros(1, dtype=torch.int32, device=dev),
+                            torch.tensor([0, idx.size], dtype=torch.int64, device=dev))
+                    mask_ptrs = (keep[1].data_ptr(), keep[0].data_ptr())
+            ids, scores = self._one_request(st.X.data_ptr() + 4 * st.X.shape[1] * uid, N, mask_ptrs, None, dev)
+            del keep
+        if filter_liked:
+            ids[scores == np.float32(_FILTERED)] = -1
+        return ids, scores
 
     @property
     def item_norms(self) -> np.ndarray:
@@ -158,10 +261,11 @@ class AlternatingLeastSquares:
             self._item_norms = n
         return self._item_norms
 
-    def recommend(self, userid, user_items, N: int = 10, filter_already_liked_items: bool = True,
+    def recommend(self, userid, user_items=None, N: int = 10, filter_already_liked_items: bool = True,
                   filter_items=None, recalculate_user: bool = False, items=None):
         """Top-N items for one user (scalar ``userid`` -> 1-D arrays) or a batch
-        (array -> 2-D arrays); ``user_items`` holds one CSR row per user.  Liked
+        (array -> 2-D arrays); ``user_items`` holds one CSR row per user (None:
+        the rows of the matrix given to ``attach_user_items``).  Liked
         items and ``filter_items`` are scored -FLT_MAX and, where fewer than N
         other items exist, fill the tail with id -1.  Returns (ids int32,
         scores float32), best first; ties by ascending item index."""
@@ -172,10 +276,16 @@ class AlternatingLeastSquares:
         if items is not None:
             raise NotImplementedError("restricting the candidate set with items= is not supported")
         scalar = np.isscalar(userid)
+        if scalar and filter_items is None:
+            return self._recommend_one(int(userid), user_items, int(N), bool(filter_already_liked_items))
         uids = np.atleast_1d(np.asarray(userid)).astype(np.int64)
+        if uids.size and (uids.min() < 0 or uids.max() >= self.user_factors.shape[0]):
+            raise IndexError("a userid is out of range")     # checked here: the device gathers without bounds checks
         mask = None
         if filter_already_liked_items or filter_items is not None:
             if filter_already_liked_items:
+                if user_items is None and self._attached is not None:
+                    user_items = self._attached[0][uids]
                 if not sp.isspmatrix_csr(user_items):
                     raise ValueError("user_items needs to be a CSR sparse matrix")
                 if user_items.shape[0] != len(uids):
@@ -193,8 +303,9 @@ class AlternatingLeastSquares:
                 mask = mask.sorted_indices()
         dev = E.require_cuda(self.device)
         with self._lock, torch.cuda.device(dev):
-            Yd = self._device_items(dev)
-            Q = E.pad_factors(self.user_factors[uids], Yd.shape[1], dev)
+            st = self._serving_state(dev)
+            Yd = st.Y
+            Q = st.X.index_select(0, torch.from_numpy(uids).to(dev))
             dmask = None if mask is None else E.DeviceCSR.from_scipy(mask, dev)
             ids, scores = E.topk(Q, Yd, int(N), dmask)
             ids = _hide_filtered(ids, scores, dmask)
@@ -231,9 +342,19 @@ class AlternatingLeastSquares:
         if recalculate_item or filter_items is not None or items is not None:
             raise NotImplementedError("only the plain similar_items(itemid, N) form is supported")
         scalar = np.isscalar(itemid)
-        iids = np.atleast_1d(np.asarray(itemid)).astype(np.int64)
-        norms = self.item_norms
         dev = E.require_cuda(self.device)
+        if scalar:
+            iid = int(itemid)
+            if not 0 <= iid < self.item_factors.shape[0]:
+                raise IndexError(f"itemid {iid} is out of range")
+            with self._lock, torch.cuda.device(dev):
+                st = self._serving_state(dev)
+                return self._one_request(st.Y.data_ptr() + 4 * st.Y.shape[1] * iid, int(N), None,
+                                         (st.norms.data_ptr(), st.norms.data_ptr() + 4 * iid), dev)
+        iids = np.atleast_1d(np.asarray(itemid)).astype(np.int64)
+        if iids.size and (iids.min() < 0 or iids.max() >= self.item_factors.shape[0]):
+            raise IndexError("an itemid is out of range")
+        norms = self.item_norms
         with self._lock, torch.cuda.device(dev):
             Yd = self._device_items(dev)
             Q = E.pad_factors(self.item_factors[iids], Yd.shape[1], dev)

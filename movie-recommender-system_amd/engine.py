@@ -362,18 +362,59 @@ class AlsEngine:
         return out
 
 
-def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = None,
-         y_norm: Optional[torch.Tensor] = None, q_norm: Optional[torch.Tensor] = None,
-         n_items: Optional[int] = None, workspace: bool = True):
-    """Fused score + top-k of every row of Q against the first n_items rows of Y.
-    Returns device tensors (ids int32 [nq, k], scores fp32 [nq, k]).  With
-    ``workspace`` the library's scratch (for the bf16-plane kernel, where it
-    applies) is taken from torch's caching allocator; results are identical
-    either way."""
+# Up to this many queries the items are split over the workgroups (mirec_topk_small); beyond it the queries
+# are (mirec_topk).  Measured crossover at 27 k items, f = 128, k = 20 (tools/probes/topk_small_crossover.py).
+SMALL_TOPK_QUERIES = 2048
+SMALL_TOPK_WS_LIMIT = 512 << 20   # ... unless the tiles' partial lists would need more than this
+
+
+def topk_small(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = None,
+               y_norm: Optional[torch.Tensor] = None, q_norm: Optional[torch.Tensor] = None,
+               n_items: Optional[int] = None, ws: Optional[torch.Tensor] = None,
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """``topk`` for a handful of queries (the serving form: one user per request): the items are split over
+    the workgroups.  Same results as ``topk``.  ``ws`` / ``out`` let a caller that serves many requests reuse
+    its buffers."""
     lib = _lib.require()
     nq, f = Q.shape
     ni = int(Y.shape[0] if n_items is None else n_items)
     assert Y.shape[1] == f and Q.is_contiguous() and Y.is_contiguous()
+    if mask is not None:
+        assert mask.shape[0] == nq, "one mask row per query"
+    if out is None:
+        out = (torch.empty((nq, k), dtype=torch.int32, device=Q.device),
+               torch.empty((nq, k), dtype=torch.float32, device=Q.device))
+    need = int(lib.mirec_topk_small_workspace_bytes(nq, ni, int(k)))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=Q.device)
+    _lib.check(lib.mirec_topk_small(_ptr(Q), nq, _ptr(Y), ni, f, _ptr(None if mask is None else mask.indptr),
+                                    _ptr(None if mask is None else mask.indices), _ptr(y_norm), _ptr(q_norm), int(k),
+                                    _ptr(out[0]), _ptr(out[1]), _ptr(ws), ws.numel(), _stream_ptr()),
+               "mirec_topk_small")
+    return out
+
+
+def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = None,
+         y_norm: Optional[torch.Tensor] = None, q_norm: Optional[torch.Tensor] = None,
+         n_items: Optional[int] = None, workspace: bool = True, path: str = "auto"):
+    """Fused score + top-k of every row of Q against the first n_items rows of Y.
+    Returns device tensors (ids int32 [nq, k], scores fp32 [nq, k]).  With
+    ``workspace`` the library's scratch (for the bf16-plane kernel, where it
+    applies) is taken from torch's caching allocator; results are identical
+    either way.  ``path``: "sweep" = the all-users kernels (queries split over
+    the workgroups), "small" = the per-request kernels (items split), "auto" =
+    by the number of queries."""
+    lib = _lib.require()
+    nq, f = Q.shape
+    ni = int(Y.shape[0] if n_items is None else n_items)
+    assert Y.shape[1] == f and Q.is_contiguous() and Y.is_contiguous()
+    assert path in ("auto", "sweep", "small")
+    if path == "auto":
+        small = 0 < nq <= SMALL_TOPK_QUERIES and k <= 224 and \
+            int(lib.mirec_topk_small_workspace_bytes(nq, ni, int(k))) <= SMALL_TOPK_WS_LIMIT
+        path = "small" if small else "sweep"
+    if path == "small":
+        return topk_small(Q, Y, k, mask, y_norm, q_norm, n_items)
     if mask is not None:
         assert mask.shape[0] == nq, "one mask row per query"
     ids = torch.empty((nq, k), dtype=torch.int32, device=Q.device)

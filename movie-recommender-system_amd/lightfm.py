@@ -50,13 +50,14 @@ class LightFMScorer:
         self.device = device
         self._lock = threading.Lock()
         self._dev = {}
+        self._serve = None   # resident state of the per-request path (recommend_request)
 
     # ------------------------------------------------------------------- state
     # The reference stores and reloads the whole model object (joblib.dump / joblib.load at
     # hybrid_docker/train.py:182 and hybrid_docker/inference.py:102): everything but the lock and the device
     # copies of the tables is plain data.
     def __getstate__(self):
-        state = {k: v for k, v in self.__dict__.items() if k not in ("_lock", "_dev")}
+        state = {k: v for k, v in self.__dict__.items() if k not in ("_lock", "_dev", "_serve")}
         state["device"] = None if self.device is None else str(self.device)
         return state
 
@@ -64,6 +65,7 @@ class LightFMScorer:
         self.__dict__.update(state)
         self._lock = threading.Lock()
         self._dev = {}
+        self._serve = None
 
     # ----------------------------------------------------------------- helpers
     def _tables(self, dev):
@@ -203,6 +205,81 @@ class LightFMScorer:
             Y = self._repr(itf, t["ie"], t["ib"], self.item_scale, W, 2, 1, 0, dev)
             ids, scores = E.topk(Q, Y, int(k))
             return ids.cpu().numpy(), scores.cpu().numpy()
+
+
+    # ---------------------------------------------------------- request path
+    def _serving_state(self, dev, user_features, item_features, k: int):
+        """What a request needs, resident on the device while the caller keeps passing the same feature matrices
+        (the reference's ``state`` dict does, hybrid_docker/inference.py:116-123): the item representations as
+        scoring rows, the user feature matrix, one query row, and output / download / workspace buffers."""
+        nc = self.no_components
+        key = (str(dev), id(user_features), getattr(user_features, "shape", None), getattr(user_features, "nnz", None),
+               id(item_features), getattr(item_features, "shape", None), getattr(item_features, "nnz", None), int(k))
+        st = self._serve
+        if st is not None and st["key"] == key:
+            return st
+        lib = _lib.require()
+        uf = self._check_features(user_features, self.user_embeddings.shape[0], self.user_embeddings.shape[0], "user")
+        itf = self._check_features(item_features, self.item_embeddings.shape[0], self.item_embeddings.shape[0], "item")
+        W = E.factor_width(nc + 2, for_scoring=True)
+        t = self._tables(dev)
+        ni = itf.shape[0]
+        st = {
+            "key": key, "hold": (user_features, item_features), "W": W, "n_users": uf.shape[0], "n_feat": uf.shape[1],
+            "Y": self._repr(itf, t["ie"], t["ib"], self.item_scale, W, 2, 1, 0, dev),
+            "uf": E.DeviceCSR.from_scipy(uf, dev),
+            "Q": torch.zeros((1, W), dtype=torch.float32, device=dev),
+            "out": torch.empty(2 * k, dtype=torch.int32, device=dev),
+            "host": torch.empty(2 * k, dtype=torch.int32).pin_memory(),
+            "ws": torch.empty(int(lib.mirec_topk_small_workspace_bytes(1, ni, int(k))), dtype=torch.uint8, device=dev),
+        }
+        self._serve = st
+        return st
+
+    def recommend_request(self, user_row, user_features, item_features=None, k: int = 20, feature_row=None):
+        """Top-k items for ONE user, the form the reference serves (hybrid_docker/inference.py:156-165,197: one
+        ``predict`` over all items and an argsort per request): ``user_row`` names a row of ``user_features``; for
+        a user without one, ``feature_row`` is its 1 x n_features CSR row (the cold-start row of
+        inference.py:66-83).  The item representations and the feature matrix stay on the device between
+        requests; a known user's request uploads nothing.  Returns (ids int32 [k], scores fp32 [k])."""
+        dev = E.require_cuda(self.device)
+        lib = _lib.require()
+        k = int(k)
+        nc = self.no_components
+        with self._lock, torch.cuda.device(dev):
+            st = self._serving_state(dev, user_features, item_features, k)
+            t = self._tables(dev)
+            keep = None
+            if feature_row is None:
+                u = int(user_row)
+                if not 0 <= u < st["n_users"]:
+                    raise IndexError(f"user row {u} is out of range")
+                d = st["uf"]
+                ptrs = (d.indptr.data_ptr() + 8 * u, d.indices.data_ptr(), d.data.data_ptr())
+            else:
+                row = sp.csr_matrix(feature_row, dtype=np.float32)
+                if row.shape != (1, st["n_feat"]):
+                    raise ValueError(f"feature_row must be 1 x {st['n_feat']}")
+                n = int(row.nnz)
+                if n and (row.indices.min() < 0 or row.indices.max() >= st["n_feat"]):
+                    raise ValueError("feature_row names a feature the model does not have")
+                keep = (torch.tensor([0, n], dtype=torch.int64, device=dev),
+                        torch.from_numpy(np.ascontiguousarray(row.indices if n else np.zeros(1), dtype=np.int32)).to(dev),
+                        torch.from_numpy(np.ascontiguousarray(row.data if n else np.zeros(1), dtype=np.float32)).to(dev))
+                ptrs = tuple(x.data_ptr() for x in keep)
+            stream = torch.cuda.current_stream().cuda_stream
+            W, Q, out = st["W"], st["Q"], st["out"]
+            _lib.check(lib.mirec_lightfm_repr(ptrs[0], ptrs[1], ptrs[2], 1, E._ptr(t["ue"]), E._ptr(t["ub"]),
+                                              self.user_scale, nc, Q.data_ptr(), W, 2, 0, 1, stream), "mirec_lightfm_repr")
+            base = out.data_ptr()
+            _lib.check(lib.mirec_topk_small(Q.data_ptr(), 1, st["Y"].data_ptr(), st["Y"].shape[0], W, 0, 0, 0, 0, k, base,
+                                            base + 4 * k, st["ws"].data_ptr(), st["ws"].numel(), stream),
+                       "mirec_topk_small")
+            st["host"].copy_(out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            arr = st["host"].numpy()
+            del keep
+            return arr[:k].copy(), arr[k:].view(np.float32).copy()
 
 
 class LightFM(LightFMScorer):
@@ -398,6 +475,7 @@ class LightFM(LightFMScorer):
                     "mirec_lightfm_warp_epoch")
                 self._examples_seen += d["nnz"]
             self._dev = {}  # device tables uploaded from older host copies are stale
+            self._serve = None
             finite = all(bool(torch.isfinite(par[n]).all().item()) for n in ("item_embeddings", "user_embeddings", "item_biases"))
         if not finite:
             raise ValueError("Not all estimated parameters are finite, your model may have diverged. "
@@ -417,6 +495,7 @@ def _param_property(name: str) -> property:
         if self.__dict__.get("_dev_par") is not None:   # a table written by the caller: the host copies lead again
             self._sync_params_to_host()
             self.__dict__["_dev_par"] = None
+        self.__dict__["_serve"] = None
         self.__dict__["_h_" + name] = value
 
     return property(getter, setter)
@@ -489,12 +568,13 @@ def compute_recommendations(user_id, state, top_k: int = 20, num_threads: int = 
     del num_threads
     model: LightFMScorer = state["model"]
     if user_id in state["user_to_idx"]:
-        ids, _ = model.recommend([state["user_to_idx"][user_id]], state["user_features"], state["item_features"], top_k)
+        ids, _ = model.recommend_request(state["user_to_idx"][user_id], state["user_features"], state["item_features"],
+                                         top_k)
     else:
         tokens = draw_cold_start_tokens(rng) if cold_start_tokens is None else list(cold_start_tokens)
         row = build_coldstart_user_row(_user_feature_mapping(state), tokens, state["user_features"].shape[1])
-        ids, _ = model.recommend(None, row, state["item_features"], top_k)
-    return [state["inv_item_map"][int(i)] for i in ids[0] if i >= 0]
+        ids, _ = model.recommend_request(None, state["user_features"], state["item_features"], top_k, feature_row=row)
+    return [state["inv_item_map"][int(i)] for i in ids if i >= 0]
 
 
 # ---------------------------------------------------------------------------

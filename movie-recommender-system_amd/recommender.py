@@ -45,6 +45,10 @@ class ALSRecommender(BaseRecommender):
         self.device = runtime.get("device")
         self.runtime_overrides = runtime
         self.hyperparameters = dict(self.metadata.get("hyperparameters", {}))
+        # The reference's contract is to answer every request, with the popular list if scoring fails
+        # (als_recommender.py:203-207); these make such failures visible to health checks and tests.
+        self.scoring_failures = 0
+        self.last_scoring_error = None
 
     # ---------------------------------------------------------------- lifecycle
     def load_model(self, model_dir: str) -> None:
@@ -75,11 +79,24 @@ class ALSRecommender(BaseRecommender):
             self.is_loaded = False
             raise
 
+    def _attach(self) -> None:
+        """Make the interaction matrix resident next to the factors, so that a request names a user and
+        nothing else: no row is sliced, uploaded or allocated per call."""
+        if getattr(self.model, "_attached", None) is None or self.model._attached[0] is not self.train_matrix:
+            self.train_matrix = self.train_matrix.tocsr()
+            if not self.train_matrix.has_sorted_indices:
+                self.train_matrix.sort_indices()
+            self.model.attach_user_items(self.train_matrix)
+            self.train_matrix = self.model._attached[0]
+
     def warmup(self) -> None:
-        """Upload the item factors and run one scoring pass so the first request
-        does not pay for it."""
+        """Upload factors and interaction matrix and run one scoring pass of each kind so the first request
+        does not pay for it.  Raises if the device path does not work: better at load time than as a silent
+        popular-list fallback on every request."""
         if self.is_loaded and self.model is not None and self.train_matrix.shape[0] > 0:
-            self.model.recommend(0, self.train_matrix[0], N=1, filter_already_liked_items=True)
+            self._attach()
+            self.model.recommend(0, None, N=20, filter_already_liked_items=True)
+            self.model.similar_items(0, N=21)
 
     def teardown(self) -> None:
         self.model = None
@@ -142,14 +159,18 @@ class ALSRecommender(BaseRecommender):
     def _recommend_for_known_user(self, user_id: str, N: int) -> RecommendationResult:
         user_idx = self.user_mappings["user_to_idx"][user_id]
         try:
-            ids, scores = self.model.recommend(user_idx, self.train_matrix[user_idx], N=N,
-                                               filter_already_liked_items=True)
+            # the reference's call, recommend(user_idx, train_matrix[user_idx], N, filter_already_liked_items=True),
+            # with the row taken from the device-resident copy of the same matrix
+            self._attach()
+            ids, scores = self.model.recommend(user_idx, None, N=N, filter_already_liked_items=True)
             idx_to_movie = self.movie_mappings["idx_to_movie"]
             recs = [{"movie_id": idx_to_movie[int(i)], "score": float(s), "rank": rank}
                     for rank, (i, s) in enumerate(zip(ids, scores), start=1) if i >= 0]
             return RecommendationResult(user_id=user_id, user_type="known", method="ALS", recommendations=recs,
                                         total_count=len(recs), model_name=self.model_name)
         except Exception as exc:  # noqa: BLE001 - same contract as the reference: never fail a request
+            self.scoring_failures += 1
+            self.last_scoring_error = repr(exc)
             self.logger.error("Error generating ALS recommendations for %s: %s", user_id, exc)
             return self._recommend_for_new_user(user_id, N)
 
@@ -175,6 +196,8 @@ class ALSRecommender(BaseRecommender):
             return SimilarItemsResult(item_id=item_id, item_type="movie", similar_items=sims, total_count=len(sims),
                                       model_name=self.model_name)
         except Exception as exc:  # noqa: BLE001
+            self.scoring_failures += 1
+            self.last_scoring_error = repr(exc)
             self.logger.error("Error finding similar movies for %s: %s", item_id, exc)
             return SimilarItemsResult(item_id=item_id, item_type="movie", similar_items=[], total_count=0,
                                       model_name=self.model_name, error=str(exc))
@@ -204,4 +227,5 @@ class ALSRecommender(BaseRecommender):
             "n_interactions": self.train_matrix.nnz,
             "sparsity": (cells - self.train_matrix.nnz) / cells * 100,
             "hyperparameters": {**self.hyperparameters, "use_gpu": self.use_gpu},
+            "scoring_failures": self.scoring_failures,
         }

@@ -1,0 +1,218 @@
+"""The serving plugin end to end on the GPU, no mocks: the behaviours the reference's own test file pins with
+mocked numerics (src/shrekommender_system/tests/test_als_recommender.py:35-84), here with a real fit and real
+scoring, every request checked against the oracle, and the popular-list fallback asserted NOT to have been
+taken.  The per-request path is the reference's real serve path: one user per call
+(recommenders/als_recommender.py:181-186, :237; api.py:26-34 calls it from a thread pool)."""
+
+import pickle
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_fixture():
+    """The artefacts of the reference's test fixture (test_als_recommender.py:12-24), integer matrix included."""
+    return {
+        "train_matrix": sp.csr_matrix([[1, 0, 1], [0, 1, 0]]),
+        "user_mappings": {"user_to_idx": {"u1": 0, "u2": 1}, "n_users": 2},
+        "movie_mappings": {"idx_to_movie": {0: "m1", 1: "m2", 2: "m3"}, "movie_to_idx": {"m1": 0, "m2": 1, "m3": 2},
+                           "n_movies": 3},
+    }
+
+
+def bigger_fixture(users=2000, movies=500):
+    from movie_recommender_system_amd import synth
+    M = synth.interactions(11, users, movies, 14.0)
+    return {
+        "train_matrix": M,
+        "user_mappings": {"user_to_idx": {f"u{u}": u for u in range(users)}, "n_users": users},
+        "movie_mappings": {"idx_to_movie": {i: f"m{i}" for i in range(movies)},
+                           "movie_to_idx": {f"m{i}": i for i in range(movies)}, "n_movies": movies},
+    }
+
+
+def trained(artefacts, hyperparameters):
+    from movie_recommender_system_amd import ALSRecommender
+    config = {"artefacts": artefacts, "hyperparameters": hyperparameters}
+    rec = ALSRecommender(config)                       # test_als_recommender.py:28-32, without the patch
+    rec.train(config)
+    return rec
+
+
+def expect_known(rec, user_id, N):
+    u = rec.user_mappings["user_to_idx"][user_id]
+    M = sp.csr_matrix(rec.train_matrix, dtype=np.float32)
+    oid, osc = oracle.topk(rec.model.user_factors[u:u + 1], rec.model.item_factors, N, liked=M[u])
+    keep = osc[0] > np.finfo(np.float32).min            # liked items pad a short list; the plugin drops them
+    return [rec.movie_mappings["idx_to_movie"][int(i)] for i in oid[0][keep]], osc[0][keep]
+
+
+def check_known(rec, user_id, N):
+    res = rec.recommend_for_user(user_id, N=N)
+    movies, scores = expect_known(rec, user_id, N)
+    assert res.user_type == "known" and res.method == "ALS", rec.last_scoring_error
+    assert [r["movie_id"] for r in res.recommendations] == movies
+    assert np.array_equal(np.array([r["score"] for r in res.recommendations], dtype=np.float32), scores)
+    assert [r["rank"] for r in res.recommendations] == list(range(1, len(movies) + 1))
+    assert res.total_count == len(movies)
+    return res
+
+
+def test_reference_fixture_all_six_behaviours(tmp_path):
+    from movie_recommender_system_amd import ALSRecommender
+    from movie_recommender_system_amd.base import ModelNotLoadedException
+    rec = trained(reference_fixture(), {"factors": 2, "iterations": 1})
+    # 1. known and new user (:35-43): u1 likes m1 and m3, so one movie is left to recommend
+    known = check_known(rec, "u1", 2)
+    assert [r["movie_id"] for r in known.recommendations] == ["m2"]
+    known2 = check_known(rec, "u2", 2)
+    assert known2.total_count == 2 and {r["movie_id"] for r in known2.recommendations} == {"m1", "m3"}
+    new = rec.recommend_for_user("new_user", N=2)
+    assert new.user_type == "new" and new.method == "most_popular" and new.total_count == 2
+    # 2. similar items (:45-53): N results, the item itself dropped
+    sim = rec.get_similar_items("m1", N=2)
+    assert sim.item_id == "m1" and sim.total_count == 2 and sim.error is None
+    assert all("movie_id" in r for r in sim.similar_items) and "m1" not in [r["movie_id"] for r in sim.similar_items]
+    assert rec.get_similar_items("mX").error is not None
+    # 3. user profile (:55-62)
+    assert rec.get_user_profile("u1")["user_type"] == "known" and rec.get_user_profile("u1")["interactions_count"] == 2
+    prof = rec.get_user_profile("unknown_user")
+    assert prof["user_type"] == "new" and prof["interactions_count"] == 0
+    # 4. stats (:64-68)
+    stats = rec.get_model_stats()
+    assert stats["n_users"] == 2 and stats["n_movies"] == 3 and stats["matrix_shape"] == (2, 3)
+    # 5. save_model (:70-78)
+    rec.save_model(str(tmp_path))
+    blob = pickle.load(open(tmp_path / "als_model.pkl", "rb"))
+    assert "model" in blob and "most_popular_movies" in blob
+    # 6. not loaded (:80-84)
+    with pytest.raises(ModelNotLoadedException):
+        ALSRecommender({"artefacts": reference_fixture(), "hyperparameters": {"factors": 2, "iterations": 1}}) \
+            .recommend_for_user("u1")
+    assert rec.scoring_failures == 0, rec.last_scoring_error
+    # the fit itself: the oracle's factors for the same seed and inputs
+    Xo, Yo = oracle.als_fit(sp.csr_matrix(reference_fixture()["train_matrix"], dtype=np.float32), factors=2,
+                            regularization=0.01, alpha=40.0, iterations=1, random_state=42)
+    assert np.allclose(rec.model.user_factors, Xo, rtol=1e-4, atol=1e-6)
+    assert np.allclose(rec.model.item_factors, Yo, rtol=1e-4, atol=1e-6)
+
+
+def test_trained_plugin_serves_requests_equal_to_the_oracle(tmp_path):
+    from movie_recommender_system_amd import ALSRecommender, artifacts
+    art = bigger_fixture()
+    rec = trained(art, {"factors": 64, "iterations": 3})
+    assert rec.model.user_factors.shape == (2000, 64) and np.isfinite(rec.model.user_factors).all()
+    for uid in ("u0", "u7", "u1999", "u512"):
+        for N in (20, 10, 1):
+            check_known(rec, uid, N)
+    pop = rec.recommend_for_user("nobody", N=20)
+    assert pop.method == "most_popular" and pop.total_count == 20
+    assert [r["movie_id"] for r in pop.recommendations] == \
+        [f"m{i}" for i in artifacts.popularity_order(art["train_matrix"], "sort_then_reverse")[:20]]
+    # similar items: cosine top-(N+1) without the item itself (als_recommender.py:237-246)
+    norms = np.linalg.norm(rec.model.item_factors, axis=-1).astype(np.float32)
+    norms[norms == 0] = 1e-10
+    for movie in ("m0", "m123", "m499"):
+        i = rec.movie_mappings["movie_to_idx"][movie]
+        sim = rec.get_similar_items(movie, N=10)
+        oid, osc = oracle.topk(rec.model.item_factors[i:i + 1], rec.model.item_factors, 11, y_norm=norms,
+                               q_norm=norms[i:i + 1])
+        assert sim.error is None and sim.total_count == 10
+        assert [r["movie_id"] for r in sim.similar_items] == [f"m{j}" for j in oid[0][1:]]
+        assert np.array_equal(np.array([r["similarity_score"] for r in sim.similar_items], dtype=np.float32), osc[0][1:])
+    assert rec.scoring_failures == 0, rec.last_scoring_error
+    # the artefact directory, then the registry's sequence: cls(config, id) -> load_model -> warmup
+    # (serving/model_registry.py:48-73), requests, teardown
+    root = artifacts.write_artifacts(tmp_path / "als@v1", art["train_matrix"], art["user_mappings"]["user_to_idx"],
+                                     art["movie_mappings"]["movie_to_idx"], rec.model)
+    import yaml
+    manifest = yaml.safe_load(open(root / "manifest.yaml"))
+    module_name, _, cls_name = manifest["class_path"].partition(":")
+    cls = getattr(__import__(module_name, fromlist=[cls_name]), cls_name)
+    config = dict(manifest["runtime"])
+    config.setdefault("artefacts", manifest["artefacts"])
+    config.setdefault("metadata", manifest["metadata"])
+    fresh = cls(config, model_name="als@v1")
+    fresh.load_model(str(root))
+    fresh.warmup()
+    assert isinstance(fresh, ALSRecommender) and fresh.health_check()["status"] == "healthy"
+    for uid in ("u3", "u1500"):
+        a, b = fresh.recommend_for_user(uid, N=20), rec.recommend_for_user(uid, N=20)
+        assert a.method == "ALS" and a.recommendations == b.recommendations
+    assert fresh.scoring_failures == 0, fresh.last_scoring_error
+    fresh.teardown()
+    assert fresh.model is None and not fresh.is_loaded
+
+
+def test_concurrent_requests_give_identical_results():
+    """api.py:26-27 is a sync endpoint: Starlette calls recommend_for_user from a pool of threads with no lock
+    of its own.  Eight threads, each asking for every 8th user and then for the same users again, interleaved
+    with similar-items requests; every answer must equal the single-threaded one."""
+    rec = trained(bigger_fixture(600, 300), {"factors": 32, "iterations": 2})
+    users = [f"u{u}" for u in range(0, 600, 3)]
+    want = {u: rec.recommend_for_user(u, N=20).recommendations for u in users}
+    want_sim = {m: rec.get_similar_items(f"m{m}", N=5).similar_items for m in range(0, 300, 30)}
+    errors = []
+
+    def worker(t):
+        try:
+            for rnd in range(2):
+                for j, u in enumerate(users[t::8]):
+                    res = rec.recommend_for_user(u, N=20)
+                    if res.method != "ALS" or res.recommendations != want[u]:
+                        errors.append((t, u, res.method))
+                    if j % 5 == 0:
+                        m = (j * 30 + 30 * t) % 300
+                        if rec.get_similar_items(f"m{m}", N=5).similar_items != want_sim[m]:
+                            errors.append((t, "sim", m))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    assert rec.scoring_failures == 0, rec.last_scoring_error
+
+
+def test_model_recommend_forms_agree():
+    """The model's call forms: a scalar user with its CSR row (the reference's call), a scalar user with the
+    attached matrix, arrays of users; out-of-range users are refused on the host."""
+    from movie_recommender_system_amd import AlternatingLeastSquares
+    rng = np.random.default_rng(8)
+    U, I, f = 300, 1000, 24
+    model = AlternatingLeastSquares(factors=f)
+    model.user_factors = rng.standard_normal((U, f)).astype(np.float32)
+    model.item_factors = rng.standard_normal((I, f)).astype(np.float32)
+    M = sp.random(U, I, density=0.02, random_state=np.random.RandomState(1), format="csr", dtype=np.float32)
+    M.sort_indices()
+    oid, osc = oracle.topk(model.user_factors, model.item_factors, 20, liked=M)
+    with pytest.raises(ValueError):
+        model.recommend(5, None, N=20)                      # nothing attached yet
+    a = model.recommend(5, M[5], N=20)
+    model.attach_user_items(M)
+    b = model.recommend(5, None, N=20)
+    c = model.recommend(np.array([5, 17, 299]), None, N=20)
+    d = model.recommend(np.array([5, 17, 299]), M[[5, 17, 299]], N=20)
+    for ids, sc in (a, b):
+        assert np.array_equal(ids, oid[5]) and np.array_equal(sc, osc[5])
+    for ids, sc in (c, d):
+        assert np.array_equal(ids, oid[[5, 17, 299]]) and np.array_equal(sc, osc[[5, 17, 299]])
+    e = model.recommend(7, None, N=20, filter_already_liked_items=False)
+    pid, psc = oracle.topk(model.user_factors[7:8], model.item_factors, 20)
+    assert np.array_equal(e[0], pid[0]) and np.array_equal(e[1], psc[0])
+    for bad in (-1, U):
+        with pytest.raises(IndexError):
+            model.recommend(bad, None, N=5)
+        with pytest.raises(IndexError):
+            model.recommend(np.array([0, bad]), None, N=5)
+    with pytest.raises(IndexError):
+        model.similar_items(I, N=5)

@@ -18,7 +18,8 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def run_topk(dev, Q, Y, k, liked=None, y_norm=None, q_norm=None, workspace=True):
+def run_topk(dev, Q, Y, k, liked=None, y_norm=None, q_norm=None, workspace=True, path="sweep"):
+    """``path``: "sweep" = the all-users kernels (the per-request kernels have tests of their own below)."""
     import torch
     from movie_recommender_system_amd import engine as E
     W = E.factor_width(Q.shape[1], for_scoring=True)
@@ -26,7 +27,7 @@ def run_topk(dev, Q, Y, k, liked=None, y_norm=None, q_norm=None, workspace=True)
     mask = None if liked is None else E.DeviceCSR.from_scipy(liked, dev)
     yn = None if y_norm is None else torch.from_numpy(y_norm).to(dev)
     qn = None if q_norm is None else torch.from_numpy(q_norm).to(dev)
-    ids, sc = E.topk(dQ, dY, k, mask, yn, qn, workspace=workspace)
+    ids, sc = E.topk(dQ, dY, k, mask, yn, qn, workspace=workspace, path=path)
     return ids.cpu().numpy(), sc.cpu().numpy()
 
 
@@ -113,6 +114,77 @@ def test_topk_plane_kernel_near_ties_and_hand_over(dev):
     ids, sc = run_topk(dev, Qp, Yinf, k)
     oid, osc = oracle.topk(Qp, Yinf, k)
     assert np.array_equal(ids, oid) and np.array_equal(sc, osc, equal_nan=True)
+
+
+@pytest.mark.parametrize("nq,ni,f,k", [
+    (1, 1, 8, 1), (1, 27000, 128, 20), (2, 27000, 64, 20), (31, 7208, 24, 20), (33, 5000, 128, 20),
+    (255, 3001, 96, 24), (1, 255, 16, 224), (9, 257, 48, 224), (3, 50, 2, 20), (17, 70001, 32, 100),
+    (1, 300, 192, 10), (8, 256, 160, 1), (64, 512, 100, 33),
+])
+def test_topk_small_matches_oracle_and_sweep(dev, nq, ni, f, k):
+    """The per-request kernels (items split over the workgroups, tiles' best merged per query): ids and scores
+    equal the oracle's and the all-users kernels', with and without the liked-item filter and the norms."""
+    rng = np.random.default_rng(13 * nq + ni + f + k)
+    Q = (rng.standard_normal((nq, f)) * rng.uniform(0.01, 3.0, (nq, 1))).astype(np.float32)
+    Y = (rng.standard_normal((ni, f)) * rng.uniform(0.01, 3.0, (ni, 1))).astype(np.float32)
+    liked = sp.random(nq, ni, density=min(0.3, 60.0 / ni), random_state=np.random.RandomState(k), format="csr",
+                      dtype=np.float32)
+    liked.sort_indices()
+    for lk in (liked, None):
+        ids, sc = run_topk(dev, Q, Y, k, lk, path="small")
+        oid, osc = oracle.topk(Q, Y, k, liked=lk)
+        assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+        ids2, sc2 = run_topk(dev, Q, Y, k, lk, path="sweep")
+        assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
+    yn = (10.0 ** rng.uniform(-2, 1, ni)).astype(np.float32)
+    qn = (10.0 ** rng.uniform(-2, 1, nq)).astype(np.float32)
+    ids, sc = run_topk(dev, Q, Y, k, None, yn, qn, path="small")
+    oid, osc = oracle.topk(Q, Y, k, y_norm=yn, q_norm=qn)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+
+
+def test_topk_small_ties_ascending_scores_and_filters(dev):
+    """What stresses the merge of the tiles' lists: scores that grow with the item index (the later tiles hold
+    all the winners, the threshold taken from the tiles' best entries admits hundreds of survivors), massive
+    exact ties (order by item index across tiles), zero queries, filters that leave fewer than k items, more
+    tiles than the threshold step looks at, infinite scores."""
+    rng = np.random.default_rng(5)
+    for ni, f, k in ((3000, 8, 20), (70000, 8, 224), (3000, 8, 100)):
+        Y = np.zeros((ni, f), dtype=np.float32)
+        Y[:, 0] = np.arange(ni, dtype=np.float32)
+        Q = np.zeros((5, f), dtype=np.float32)
+        Q[:, 0] = 1.0
+        Q[2:, 0] = -1.0
+        Q[4, 0] = 0.0
+        ids, sc = run_topk(dev, Q, Y, k, path="small")
+        oid, osc = oracle.topk(Q, Y, k)
+        assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    ni, nq, f, k = 4000, 40, 32, 20
+    Yi = rng.integers(-1, 2, (ni, f)).astype(np.float32)
+    Qi = rng.integers(-1, 2, (nq, f)).astype(np.float32)
+    ids, sc = run_topk(dev, Qi, Yi, k, path="small")
+    oid, osc = oracle.topk(Qi, Yi, k)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    Yr = rng.standard_normal((700, 64)).astype(np.float32)
+    Qr = rng.standard_normal((70, 64)).astype(np.float32)
+    dense = np.zeros((70, 700), dtype=np.float32)
+    dense[3, :] = 1
+    dense[40, 5:] = 1
+    dense[69, : 700 - (k - 1)] = 1
+    dense[10, ::7] = 1
+    liked = sp.csr_matrix(dense)
+    ids, sc = run_topk(dev, Qr, Yr, k, liked, path="small")
+    oid, osc = oracle.topk(Qr, Yr, k, liked=liked)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    ids, sc = run_topk(dev, Qr[:3], Yr[:7], k, path="small")          # fewer items than k
+    oid, osc = oracle.topk(Qr[:3], Yr[:7], k)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc) and (ids[:, 7:] == -1).all()
+    Yinf = Yr.copy()
+    Yinf[17, 3] = np.inf
+    Yinf[400, 5] = -np.inf
+    ids, sc = run_topk(dev, np.abs(Qr), Yinf, k, path="small")
+    oid, osc = oracle.topk(np.abs(Qr), Yinf, k)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
 
 
 def test_topk_full_size_both_kernels_agree(dev):

@@ -3,7 +3,7 @@
 usage: python tools/fuzz_parity.py [--seconds 240] [--seed 1] [--kind topk|sweep|both|exact|lightfm|warp|data] [--cases M] [--case N]
 
 Draws shapes, widths, k, filters, value scales and tie patterns at random and compares
-  top-K (both kernels)      ids and scores, bit for bit
+  top-K (all three kernels) ids and scores, bit for bit (the two all-users kernels and the per-request one)
   ALS half-sweep            relative Frobenius distance <= 2e-5 (the tolerance of the parity tests); beyond
                             it, every row within 20x the distance at which plain fp32 numpy CG lands from float64,
                             and rows of low-rank systems within 100x the oracle's squared error in the A-norm
@@ -93,12 +93,12 @@ def case_topk(rng):
         desc += " norms=" + ("both" if qn is not None else "items")
     oid, osc = oracle.topk(Q, Y, k, liked=liked, y_norm=yn, q_norm=qn)
     ok = True
-    for ws in (True, False):
-        ids, sc = E.topk(dQ, dY, k, mask, dyn, dqn, workspace=ws)
+    for ws, path in ((True, "sweep"), (False, "sweep"), (True, "small")):
+        ids, sc = E.topk(dQ, dY, k, mask, dyn, dqn, workspace=ws, path=path)
         ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
         if not (np.array_equal(ids, oid) and np.array_equal(sc, osc)):
             bad = np.nonzero((ids != oid).any(1) | (sc != osc).any(1))[0]
-            print(f"FAIL {desc} W={W} workspace={ws}: {bad.size} rows differ, first {bad[:5].tolist()}", flush=True)
+            print(f"FAIL {desc} W={W} workspace={ws} path={path}: {bad.size} rows differ, first {bad[:5].tolist()}", flush=True)
             if VERBOSE:
                 r = int(bad[0])
                 pos = np.nonzero((ids[r] != oid[r]) | (sc[r] != osc[r]))[0]
