@@ -226,3 +226,163 @@ def test_lightfm_request_path_signature_and_cold_start_draw():
     from types import SimpleNamespace
     assert L._user_feature_mapping({"dataset": SimpleNamespace(_user_feature_mapping=fmap)}) is fmap
     assert L._user_feature_mapping({"user_feature_mapping": {"a": 1}, "dataset": None}) == {"a": 1}
+
+
+def _golden_interface():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "plugin_interface.json")))
+
+
+def test_plugin_interface_equals_the_reference_golden():
+    """tests/golden/plugin_interface.json was written from the reference's own recommenders/base.py (loaded by
+    path in the build container, tests/golden/make_plugin_interface.py): abstract methods, signatures, result
+    dataclasses, to_dict outputs, health_check dictionaries, exceptions, optional hooks.  The interface module
+    used outside the reference's environment and the plugin class are held to it."""
+    import dataclasses
+    import inspect
+    from movie_recommender_system_amd import base as B
+    gold = _golden_interface()
+    assert not B.HAVE_REFERENCE_BASE
+    Base = B.BaseRecommender
+    assert sorted(Base.__abstractmethods__) == gold["abstract_methods"]
+    mine = {n: str(inspect.signature(f)) for n, f in inspect.getmembers(Base, inspect.isfunction)
+            if not n.startswith("_") or n == "__init__"}
+    assert mine == gold["method_signatures"]
+    for name, fields in gold["dataclasses"].items():
+        got = [{"name": f.name, "type": str(f.type),
+                "default": None if f.default is dataclasses.MISSING else repr(f.default),
+                "has_default": f.default is not dataclasses.MISSING} for f in dataclasses.fields(getattr(B, name))]
+        assert got == fields, name
+    rec = B.RecommendationResult("u1", "known", "ALS", [{"movie_id": "m2", "score": 0.5, "rank": 1}], 1, "als@v1")
+    ok = B.SimilarItemsResult("m1", "movie", [{"movie_id": "m3", "similarity_score": 0.25, "rank": 1}], 1, "als@v1")
+    err = B.SimilarItemsResult("mX", "movie", [], 0, "als@v1", error="Movie not found in training data")
+    assert {"recommendation": rec.to_dict(), "similar_ok": ok.to_dict(), "similar_error": err.to_dict()} == gold["to_dict"]
+    for name, bases in gold["exceptions"].items():
+        assert [b.__name__ for b in getattr(B, name).__mro__[1:-1]] == bases
+
+    class Stub(Base):
+        stats = {"n_users": 2}
+
+        def load_model(self, model_dir):
+            self.is_loaded = True
+
+        def recommend_for_user(self, user_id, N=10):
+            return None
+
+        def get_similar_items(self, item_id, N=10):
+            return None
+
+        def get_user_profile(self, user_id):
+            return {}
+
+        def get_model_stats(self):
+            if isinstance(self.stats, Exception):
+                raise self.stats
+            return self.stats
+
+    s = Stub({"k": 1}, "stub@v1")
+    assert {"config": s.config, "model_name": s.model_name, "logger_suffix": s.logger.name.rsplit(".", 1)[-1]} == \
+        gold["constructor_state"]
+    health = {"not_loaded": s.health_check()}
+    s.load_model("x")
+    health["healthy"] = s.health_check()
+    s.stats = {}
+    health["empty_stats"] = s.health_check()
+    s.stats = RuntimeError("boom")
+    health["stats_raise"] = s.health_check()
+    assert health == gold["health_check"]
+    hooks = {"warmup": s.warmup(), "teardown": s.teardown()}
+    for name, call in (("save_model", lambda: s.save_model("d")), ("train", lambda: s.train({}))):
+        with pytest.raises(NotImplementedError) as info:
+            call()
+        hooks[name] = {"raises": "NotImplementedError", "message": str(info.value)}
+    assert hooks == gold["optional_hooks"]
+    with pytest.raises(TypeError):
+        Base({}, "x")
+    # the plugin: concrete, same public methods with the same parameters as the interface declares
+    assert not inspect.isabstract(ALSRecommender)
+    for name, sig in gold["method_signatures"].items():
+        if name in ("__init__", "train"):
+            continue            # the plugin gives model_name a default and train a named parameter, as the reference's does
+        assert str(inspect.signature(getattr(ALSRecommender, name))) == sig, name
+    assert str(inspect.signature(ALSRecommender.__init__)) == "(self, config: 'Dict[str, Any]', model_name: 'str' = 'als')"
+    assert str(inspect.signature(ALSRecommender.train)) == "(self, training_config: 'Dict[str, Any]') -> 'None'"
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-device failure mode of warmup")
+def test_registry_sequence_fails_loudly_at_warmup_without_a_device(tmp_path, dummy_artefacts):
+    """serving/model_registry.py:48-73: cls(config, model_name=id) -> load_model -> warmup.  Loading is I/O and
+    works anywhere; warmup touches the device and must raise here rather than leave a model that answers every
+    request from the popular list."""
+    rec = loaded_plugin(dummy_artefacts)
+    root = artifacts.write_artifacts(tmp_path / "als@v1", rec.train_matrix, rec.user_mappings["user_to_idx"],
+                                     rec.movie_mappings["movie_to_idx"], rec.model)
+    import yaml
+    manifest = yaml.safe_load(open(root / "manifest.yaml"))
+    module_name, _, cls_name = manifest["class_path"].partition(":")
+    cls = getattr(__import__(module_name, fromlist=[cls_name]), cls_name)
+    config = dict(manifest["runtime"])
+    config.setdefault("artefacts", manifest["artefacts"])
+    config.setdefault("metadata", manifest["metadata"])
+    inst = cls(config, model_name="als@v1")
+    inst.load_model(str(root))
+    assert inst.is_loaded
+    with pytest.raises(_lib.MirecError, match="no HIP device"):
+        inst.warmup()
+
+
+REFERENCE_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE_SRC, "shrekommender_system")),
+                    reason="needs the reference tree (present in the build container only)")
+def test_inside_the_reference_environment():
+    """With the reference's package importable -- `implicit` resolved by this package's stand-in
+    (movie_recommender_system_amd/compat), as a deployment that has no implicit wheel would do it -- the plugin
+    subclasses the REFERENCE's BaseRecommender (what serving/model_registry.py:116-117 checks), the registry's
+    own `_resolve_class` accepts the manifest's class_path, the reference's unmodified ALSRecommender builds
+    this package's model, and the reference's own test file for the plugin passes.  Runs in child processes:
+    this process has already imported the interface without the reference."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "movie_recommender_system_amd", "compat"), REFERENCE_SRC, ROOT]))
+    code = """
+import implicit, implicit.als
+from shrekommender_system.recommenders import base as RB
+from shrekommender_system.recommenders.als_recommender import ALSRecommender as RefPlugin
+from movie_recommender_system_amd import base as B, ALSRecommender, AlternatingLeastSquares
+assert B.HAVE_REFERENCE_BASE and B.BaseRecommender is RB.BaseRecommender
+assert issubclass(ALSRecommender, RB.BaseRecommender)
+assert B.RecommendationResult is RB.RecommendationResult and B.ModelNotLoadedException is RB.ModelNotLoadedException
+assert implicit.als.AlternatingLeastSquares is AlternatingLeastSquares
+import importlib
+module_name, _, class_name = "movie_recommender_system_amd.recommender:ALSRecommender".partition(":")
+cls = getattr(importlib.import_module(module_name), class_name)
+assert issubclass(cls, RB.BaseRecommender)          # serving/model_registry.py:109-118, step for step
+inst = cls({"use_gpu": True, "artefacts": {}, "metadata": {}}, model_name="als@v1")
+assert inst.health_check() == {"model_name": "als@v1", "status": "unhealthy", "reason": "Model not loaded"}
+import numpy as np, scipy.sparse as sp
+ref = RefPlugin({"artefacts": {}, "hyperparameters": {"factors": 2, "iterations": 1}})
+ref.train_matrix = sp.csr_matrix([[1, 0, 1], [0, 1, 0]])
+try:
+    ref._train_model({"factors": 2, "iterations": 1})
+    raise SystemExit("a fit without a device must fail")
+except Exception as exc:
+    assert type(exc).__name__ == "MirecError" and "no HIP device" in str(exc), exc
+m = ref.model
+assert isinstance(m, AlternatingLeastSquares) and (m.factors, m.iterations, m.regularization, m.alpha, m.random_state) == (2, 1, 0.01, 40.0, 42)
+print("ok")
+"""
+    if NO_GPU:
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stdout + res.stderr
+    ref_test = os.path.join(REFERENCE_SRC, "shrekommender_system", "tests", "test_als_recommender.py")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", ref_test], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    # Five of its six tests pass.  The sixth, test_save_model (:70-78), pickles the autospec'd mock that stands for
+    # the model, which unittest.mock cannot do for ANY class behind the mock (pickle rejects the mock's borrowed
+    # __class__: "args[0] from __newobj__ args has the wrong class"), the real implicit class included; with a
+    # real model object instead of the mock the same save / load is exercised by this suite's own tests.
+    assert "5 passed" in res.stdout and "1 failed" in res.stdout, res.stdout + res.stderr
+    assert "test_save_model" in res.stdout and "PicklingError" in res.stdout, res.stdout + res.stderr
