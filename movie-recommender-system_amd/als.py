@@ -14,6 +14,7 @@ that the pickle needs nothing but this package to load.
 
 from __future__ import annotations
 
+import os
 import threading
 from typing import Optional
 
@@ -80,7 +81,11 @@ class AlternatingLeastSquares:
     def __init__(self, factors: int = 100, regularization: float = 0.01, alpha: float = 1.0, dtype=np.float32,
                  use_native: bool = True, use_cg: bool = True, use_gpu: bool = True, iterations: int = 15,
                  calculate_training_loss: bool = False, num_threads: int = 0, random_state=None,
-                 cg_steps: int = 3, device=None):
+                 cg_steps: int = 3, device=None, devices=None):
+        """``device``: the HIP device of a single-GPU fit and of scoring (default: the current one).
+        ``devices``: a list of device indices, one rank each, for a fit sharded over the GPUs of one node
+        (``fit`` then runs in child processes, see ``_fit_sharded``); scoring uses ``device`` or the first of
+        them."""
         if np.dtype(dtype) != np.float32:
             raise ValueError("only float32 factors are supported")
         self.factors = int(factors)
@@ -95,7 +100,10 @@ class AlternatingLeastSquares:
         self.num_threads = num_threads
         self.random_state = random_state
         self.cg_steps = int(cg_steps)
-        self.device = device
+        self.devices = None if devices is None else [int(d) for d in devices]
+        if self.devices is not None and not self.devices:
+            raise ValueError("devices must name at least one device")
+        self.device = device if device is not None or not self.devices else f"cuda:{self.devices[0]}"
         self.user_factors: Optional[np.ndarray] = None
         self.item_factors: Optional[np.ndarray] = None
         self._reset_caches()
@@ -114,13 +122,14 @@ class AlternatingLeastSquares:
             "iterations": self.iterations, "random_state": self.random_state, "cg_steps": self.cg_steps,
             "use_native": self.use_native, "use_cg": self.use_cg, "use_gpu": self.use_gpu,
             "calculate_training_loss": self.calculate_training_loss, "num_threads": self.num_threads,
-            "device": None, "dtype": "float32",
+            "device": None, "devices": self.devices, "dtype": "float32",
             "user_factors": None if self.user_factors is None else np.asarray(self.user_factors, dtype=np.float32),
             "item_factors": None if self.item_factors is None else np.asarray(self.item_factors, dtype=np.float32),
         }
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.setdefault("devices", None)
         self.dtype = np.dtype(np.float32)
         self._reset_caches()
 
@@ -143,6 +152,18 @@ class AlternatingLeastSquares:
             self.item_factors = rs.rand(items, self.factors).astype(np.float32) * 0.01
         if self.user_factors.shape != (users, self.factors) or self.item_factors.shape != (items, self.factors):
             raise ValueError("user_factors / item_factors do not match the matrix shape")
+        if not self.use_cg and Cui.nnz and float(np.abs(Cui.data).min()) * abs(self.alpha) < 1.0:
+            raise ValueError("use_cg=False needs |value| * alpha >= 1 for every stored entry "
+                             "(smaller confidences can make a row's system indefinite)")
+        # rows longer than this are summed chunk by chunk: fixed by the whole matrix, so that one GPU and any
+        # number of ranks add the same partial sums in the same order
+        chunk = E.auto_chunk(Cui.nnz)
+        if self.devices is not None and len(self.devices) > 1:
+            if callback is not None:
+                raise ValueError("callback is not supported by a fit sharded over several devices")
+            self._fit_sharded(Cui, chunk)
+            self._dev_items = self._item_norms = self._serving = None
+            return
 
         with self._lock, torch.cuda.device(dev):
             F = E.factor_width(self.factors)
@@ -150,13 +171,10 @@ class AlternatingLeastSquares:
             X = E.pad_factors(self.user_factors, F, dev)
             Y = E.pad_factors(self.item_factors, F, dev)
             if self.use_cg:
-                eng = E.AlsEngine(dCui, None, X, Y, self.regularization, self.cg_steps)
+                eng = E.AlsEngine(dCui, None, X, Y, self.regularization, self.cg_steps, chunk_nnz=chunk)
             else:
-                if Cui.nnz and float(np.abs(Cui.data).min()) * abs(self.alpha) < 1.0:
-                    raise ValueError("use_cg=False needs |value| * alpha >= 1 for every stored entry "
-                                     "(smaller confidences can make a row's system indefinite)")
                 # every row with entries goes through the explicit-Gram kernel, which holds the Cholesky solve
-                eng = E.AlsEngine(dCui, None, X, Y, self.regularization, self.SOLVE_EXACT, short_max=0)
+                eng = E.AlsEngine(dCui, None, X, Y, self.regularization, self.SOLVE_EXACT, short_max=0, chunk_nnz=chunk)
             for it in range(self.iterations):
                 eng.iteration()
                 if callback is not None:
@@ -166,6 +184,81 @@ class AlternatingLeastSquares:
             self._dev_items = None
             self._item_norms = None
             self._serving = None
+
+    def _fit_sharded(self, Cui: sp.csr_matrix, chunk_nnz: int, timeout_s: float = 6 * 3600.0) -> None:
+        """The fit on ``len(self.devices)`` ranks, one fresh child process per entry of ``devices`` (started
+        with nothing of this process's GPU state: a process that has initialised the GPU must never be replaced
+        by another program, and RCCL wants one process per device anyway).  Inputs and results travel through a
+        scratch directory in shared memory; the children run ``fit_worker``.  Two entries that name the same
+        card make the ranks talk over gloo through host memory (RCCL refuses two ranks on one device): the
+        sharding is the same, so the factors are, bit for bit -- which is what the tests check on one GPU."""
+        import json
+        import shutil
+        import socket
+        import subprocess
+        import sys
+        import tempfile
+        import time
+
+        world = len(self.devices)
+        backend = "nccl" if len(set(self.devices)) == world else "gloo"
+        pkg_dir = os.path.dirname(os.path.abspath(__file__))
+        scratch = tempfile.mkdtemp(prefix="mirec_fit_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        procs = []
+        try:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            np.save(os.path.join(scratch, "indptr.npy"), np.ascontiguousarray(Cui.indptr, dtype=np.int64))
+            np.save(os.path.join(scratch, "indices.npy"), np.ascontiguousarray(Cui.indices, dtype=np.int32))
+            np.save(os.path.join(scratch, "data.npy"), np.ascontiguousarray(Cui.data, dtype=np.float32))
+            np.save(os.path.join(scratch, "x0.npy"), np.ascontiguousarray(self.user_factors, dtype=np.float32))
+            np.save(os.path.join(scratch, "y0.npy"), np.ascontiguousarray(self.item_factors, dtype=np.float32))
+            with open(os.path.join(scratch, "job.json"), "w") as fh:
+                json.dump({"devices": self.devices, "backend": backend, "port": port, "users": Cui.shape[0],
+                           "items": Cui.shape[1], "factors": self.factors, "alpha": self.alpha,
+                           "regularization": self.regularization, "cg_steps": self.cg_steps, "use_cg": bool(self.use_cg),
+                           "iterations": self.iterations, "chunk_nnz": int(chunk_nnz)}, fh)
+            env = dict(os.environ)
+            env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(pkg_dir)] + [p for p in [env.get("PYTHONPATH")] if p])
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            module = __name__.rsplit(".", 1)[0] + ".fit_worker"
+            for r in range(world):
+                log = open(os.path.join(scratch, f"rank{r}.log"), "w")
+                procs.append((subprocess.Popen([sys.executable, "-m", module, scratch, str(r)], env=env, stdout=log,
+                                               stderr=subprocess.STDOUT), log))
+            deadline = time.time() + timeout_s
+            failed = None
+            while failed is None and any(p.poll() is None for p, _ in procs):
+                for r, (p, _) in enumerate(procs):
+                    if p.poll() not in (None, 0):
+                        failed = r
+                if time.time() > deadline:
+                    failed = -1
+                time.sleep(0.05)
+            if failed is None:
+                failed = next((r for r, (p, _) in enumerate(procs) if p.returncode != 0), None)
+            if failed is not None:
+                for p, _ in procs:      # the ranks this call started, by handle
+                    if p.poll() is None:
+                        p.kill()
+                for p, lg in procs:
+                    p.wait()
+                    lg.close()
+                r = max(failed, 0)
+                tail = open(os.path.join(scratch, f"rank{r}.log")).read()[-2000:]
+                raise _lib.MirecError(("sharded fit timed out" if failed < 0 else f"rank {r} of the sharded fit failed")
+                                      + f" (devices {self.devices}, backend {backend}):\n{tail}")
+            for _, lg in procs:
+                lg.close()
+            self.user_factors = np.load(os.path.join(scratch, "x_out.npy"))
+            self.item_factors = np.load(os.path.join(scratch, "y_out.npy"))
+        finally:
+            for p, _ in procs:
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
+            shutil.rmtree(scratch, ignore_errors=True)
 
     # -------------------------------------------------------------- inference
     def _device_items(self, dev: torch.device):

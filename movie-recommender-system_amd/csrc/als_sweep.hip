@@ -315,16 +315,25 @@ __device__ void chol_solve_block(float* A, const float* b, float* pan, float* xg
     constexpr int LDA = F + 1;
     constexpr int NBLK = F / 4;
     constexpr int NB = NBLK * (NBLK + 1) / 2 + NBLK;  // lower-triangle blocks + those of the row that carries b
-    constexpr int NBK = (NB + NTHR - 1) / NTHR;       // blocks per thread
+    // Threads that own blocks: all of them where that gives every thread two blocks or more (F >= 128), else the
+    // first OWN, a whole number of wavefronts with two blocks each (F = 64: 128 of 256 threads, F = 96: 192 of 384).
+    // With ONE block per thread and the blocks spread over three or more wavefronts (F = 64, 96) about 3 in 10^4
+    // solves came out different from run to run whenever other workgroups shared the compute unit (none with a
+    // workgroup per unit, none when the routine runs alone, A and b verified equal at entry, extra barriers, scalar
+    // panel stores and panels in LDS of their own changed nothing: tools/probes/exact_repro.py, chol_standalone.hip);
+    // the cause was not established.  With two blocks per owner: 0 differences in 6 x 10^5 solves per width.
+    constexpr int OWN = ((NB + NTHR - 1) / NTHR >= 2) ? NTHR : (NB / 2 + 63) / 64 * 64;
+    static_assert(OWN <= NTHR && OWN % 64 == 0, "owners are whole wavefronts of the workgroup");
+    constexpr int NBK = (NB + OWN - 1) / OWN;         // blocks per owning thread
     constexpr int PB = 4 * (F + 4);                   // floats of one panel buffer
     float a[NBK][4][4];
     int bi[NBK], bj[NBK];  // block row / block column; bi == NBLK: the b row; bj == -1: no block
 #pragma unroll
     for (int s = 0; s < NBK; ++s) {
-        const int id = tid + s * NTHR;
+        const int id = tid + s * OWN;
         bi[s] = 0;
         bj[s] = -1;
-        if (id < NB) {
+        if (id < NB && tid < OWN) {
             // first id of block column c: c (NBLK + 1) - c (c - 1) / 2  (rows c .. NBLK)
             const float h = (float)NBLK + 1.5f;
             int c = (int)(h - sqrtf(h * h - 2.f * (float)id));
@@ -517,7 +526,7 @@ struct GramCfg {
     // The exact solver's two panel buffers (2 * 4 * (F + 4) floats) overlay everything from the b partials on
     // -- all of it dead once b is in registers -- or, at F = 32, the part of the tile area that A leaves free.
     static constexpr int CHOL_PANEL = (FLOATS - BRED >= 8 * (F + 4)) ? BRED : F * LDX;
-    static_assert(CHOL_PANEL % 4 == 0 && CHOL_PANEL + 8 * (F + 4) <= (CHOL_PANEL == BRED ? FLOATS : BIGN),
+    static_assert(CHOL_PANEL % 4 == 0 && CHOL_PANEL + 8 * (F + 4) <= (CHOL_PANEL == F * LDX ? BIGN : FLOATS),
                   "no room for the panels of the exact solver");
     // first tile id of band-row b in the row-major enumeration of the upper triangle
     static constexpr int row_start(int b) { return b * NB - b * (b - 1) / 2; }

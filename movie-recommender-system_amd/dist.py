@@ -108,7 +108,7 @@ def allgather_rows(T: torch.Tensor, bounds: Sequence[int], rank: int, group=None
         if scratch is not None:
             scratch.update(key=key, send=send, recv=recv)
     send[:sizes[rank]].copy_(T[bounds[rank]:bounds[rank + 1]])
-    dist.all_gather(list(recv.chunk(world, dim=0)), send, group=group)
+    all_gather_list(list(recv.chunk(world, dim=0)), send, group=group)
     for r in range(world):
         if r != rank and sizes[r]:
             T[bounds[r]:bounds[r + 1]].copy_(recv[r * mx:r * mx + sizes[r]])
@@ -116,6 +116,33 @@ def allgather_rows(T: torch.Tensor, bounds: Sequence[int], rank: int, group=None
 
 def _is_nccl(group=None) -> bool:
     return dist.get_backend(group) == "nccl"
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """``dist.all_gather_into_tensor``; device tensors on a backend that cannot take them (gloo: ranks that share
+    one card, where RCCL refuses to run) go through host memory, synchronously."""
+    if out.is_cuda and not _is_nccl(group):
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, inp.detach().cpu(), group=group)
+        out.copy_(host_out)
+        return _Done()
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+
+
+def all_gather_list(outs, inp: torch.Tensor, group=None):
+    """``dist.all_gather`` with the same host staging."""
+    if inp.is_cuda and not _is_nccl(group):
+        host = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(host, inp.detach().cpu(), group=group)
+        for o, h in zip(outs, host):
+            o.copy_(h)
+        return
+    dist.all_gather(outs, inp, group=group)
 
 
 def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -202,7 +229,16 @@ def shard_item_rows(blocks, users: "BlockCyclic", n_items: int, rank: int, group
     from .engine import DeviceCSR
 
     if world == 1:
-        (_, _, whole), = blocks
+        if len(blocks) == 1:
+            whole = blocks[0][2]
+        else:   # one rank that holds its rows as several blocks: string them together, in row order
+            ptrs, base = [torch.zeros(1, dtype=torch.int64, device=dev)], 0
+            for _, _, c in blocks:
+                p = c.indptr - c.indptr[0]
+                ptrs.append(p[1:] + base)
+                base += int(p[-1])
+            whole = DeviceCSR(torch.cat(ptrs), torch.cat([c.indices for _, _, c in blocks]),
+                              torch.cat([c.data for _, _, c in blocks]), (users.nrows, n_items))
         return transpose(whole), bounds
 
     # ---- split this rank's entries by destination item range
@@ -296,8 +332,7 @@ class ShardedAlsDriver:
                 s0, s1 = u.slab(j)
                 p0, p1 = u.block(j, r)
                 # async: the collective waits for the solve just enqueued and runs beside the next block's
-                pending.append(dist.all_gather_into_tensor(self.Xpad[s0:s1], self.Xpad[p0:p1], group=self.group,
-                                                           async_op=True))
+                pending.append(all_gather_into(self.Xpad[s0:s1], self.Xpad[p0:p1], group=self.group, async_op=True))
         t0 = self._mark()
         for w in pending:
             w.wait()

@@ -154,6 +154,13 @@ def gram(Y: torch.Tensor, reg: float, out: Optional[torch.Tensor] = None, ws: Op
     return out
 
 
+def auto_chunk(nnz: int) -> int:
+    """The chunk length the library chooses for a matrix of ``nnz`` stored entries (rows longer than it are cut
+    into chunks whose partial sums are added in chunk order).  A sharded fit passes the value of the WHOLE
+    matrix to every rank, so that the sums, and with them the result bits, do not depend on the world size."""
+    return int(min(max((int(nnz) // 16384 + 31) // 32 * 32, 4096), 1 << 20))
+
+
 # The matrix-free kernel re-reads a row's gathered factor rows on every CG step.  That is cheap while the
 # gathered table sits in L2 / Infinity Cache and a 4x HBM bill once it does not, so rows of any length go
 # to it only below this table size; above it only rows that fit its LDS cache do.

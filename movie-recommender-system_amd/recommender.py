@@ -43,6 +43,9 @@ class ALSRecommender(BaseRecommender):
         self.metadata = runtime.pop("metadata", {})
         self.use_gpu = runtime.get("use_gpu", True)
         self.device = runtime.get("device")
+        # manifest `runtime: {devices: [0, 1, ...]}` (forwarded verbatim by serving/model_registry.py:58-62): the
+        # GPUs a fit is sharded over, one rank each; scoring runs on `device`, or on the first of them
+        self.devices = runtime.get("devices")
         self.runtime_overrides = runtime
         self.hyperparameters = dict(self.metadata.get("hyperparameters", {}))
         # The reference's contract is to answer every request, with the popular list if scoring fails
@@ -120,7 +123,8 @@ class ALSRecommender(BaseRecommender):
         hp = {**self.DEFAULT_HYPERPARAMETERS, **hyperparameters}
         self.model = AlternatingLeastSquares(
             factors=hp["factors"], iterations=hp["iterations"], regularization=hp["regularization"],
-            alpha=hp["alpha"], random_state=hp["random_state"], use_gpu=True, device=self.device)
+            alpha=hp["alpha"], random_state=hp["random_state"], use_gpu=True, device=self.device,
+            devices=self.devices)
         self.model.fit(self.train_matrix)
         self.most_popular_movies = popularity_order(self.train_matrix, "sort_then_reverse")
 

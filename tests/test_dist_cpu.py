@@ -150,3 +150,23 @@ def test_odd_worlds_and_shards_without_rows(tmp_path, world, nu, ni, blocks):
         got = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(got["X"], Xr), r
         assert np.array_equal(got["Y"], Yr), r
+
+
+def test_one_rank_with_several_blocks_strings_them_together():
+    """A single rank may hold its user rows as several blocks (no process group exists then): the item-row
+    shard is the transpose of the blocks strung together in row order."""
+    from movie_recommender_system_amd.engine import DeviceCSR
+    nu, ni = 200, 60
+    users = D.BlockCyclic(nu, 1, blocks=3)
+    shards = []
+    for a, b in users.owned(0):
+        ip, ix, dt = synth.interactions_torch(5, nu, ni, 6.0, "cpu", users=(a, b))
+        shards.append((a, b, DeviceCSR(ip, ix, dt, (b - a, ni))))
+    assert len(shards) == 3 and sum(b - a for a, b, _ in shards) == nu
+    ciu, ib = D.shard_item_rows(shards, users, ni, 0, transpose=_cpu_transpose)
+    want = sp.csr_matrix(synth.interactions(5, nu, ni, 6.0).T)
+    want.sort_indices()
+    got = ciu.to_scipy()
+    assert ib == [0, ni] and got.shape == want.shape
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    assert np.array_equal(got.data, want.data)

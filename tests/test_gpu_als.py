@@ -525,3 +525,72 @@ def test_wide_addressing_gives_the_same_bits(dev, rows, cols, f, dens):
     Xo = X.copy()
     oracle.als_half_sweep(C, Xo, Y, 0.01, 3)
     assert rel(wide.cpu().numpy(), Xo) < 2e-5
+
+
+@pytest.mark.timeout(600)
+def test_fit_sharded_over_devices_equals_single_device_fit(dev):
+    """`AlternatingLeastSquares(devices=[...])` -- what a manifest's `runtime: {devices: [...]}` reaches through the
+    plugin -- runs the fit on one rank per entry in child processes.  Entries that name the same card make the
+    ranks share it (host-staged gloo exchange, RCCL refuses two ranks per device); the sharding, the solves and
+    the order of every sum are those of a multi-GPU run, so the factors must equal the single-device fit's bit
+    for bit -- with the CG steps and with the exact solver, on two and on three ranks, and through the plugin."""
+    from movie_recommender_system_amd import ALSRecommender, AlternatingLeastSquares, synth
+    M = synth.interactions(21, 5000, 700, 30.0)
+    kw = dict(factors=64, regularization=0.01, alpha=40.0, iterations=3, random_state=42)
+    one = AlternatingLeastSquares(**kw)
+    one.fit(M)
+    for devices in ([0, 0], [0, 0, 0]):
+        many = AlternatingLeastSquares(devices=devices, **kw)
+        many.fit(M)
+        assert np.array_equal(many.user_factors, one.user_factors), devices
+        assert np.array_equal(many.item_factors, one.item_factors), devices
+    ex1 = AlternatingLeastSquares(use_cg=False, **kw)
+    ex1.fit(M)
+    ex2 = AlternatingLeastSquares(use_cg=False, devices=[0, 0], **kw)
+    ex2.fit(M)
+    assert np.array_equal(ex2.user_factors, ex1.user_factors) and np.array_equal(ex2.item_factors, ex1.item_factors)
+    assert not np.array_equal(ex1.user_factors, one.user_factors)
+    # through the plugin, as the registry hands the manifest's runtime section to it
+    art = {"train_matrix": M, "user_mappings": {"user_to_idx": {f"u{u}": u for u in range(5000)}, "n_users": 5000},
+           "movie_mappings": {"idx_to_movie": {i: f"m{i}" for i in range(700)},
+                              "movie_to_idx": {f"m{i}": i for i in range(700)}, "n_movies": 700}}
+    rec = ALSRecommender({"use_gpu": True, "devices": [0, 0], "artefacts": {}, "metadata": {}}, "als@v1")
+    rec.train({"artefacts": art, "hyperparameters": {"factors": 64, "iterations": 3}})
+    assert np.array_equal(rec.model.user_factors, one.user_factors)
+    res = rec.recommend_for_user("u17", N=20)
+    assert res.method == "ALS" and res.total_count == 20 and rec.scoring_failures == 0
+    # a rank that fails is reported with its log, not as a hang
+    bad = AlternatingLeastSquares(devices=[99, 99], **kw)
+    with pytest.raises(Exception, match="sharded fit"):
+        bad.fit(M)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("f", [32, 64, 96, 128, 192])
+def test_half_sweeps_give_the_same_bits_every_run(dev, f):
+    """The same half-sweep from the same inputs, eight times over 20 000 rows (many workgroups per compute unit,
+    so that workgroups of different rows keep replacing each other): every run must give the bits of the first --
+    the CG kernels and the exact (Cholesky) solver, rows solved in one piece and rows split into chunks.  (The
+    exact solver at widths 64 and 96 once failed this in about 3 of 10^4 rows.)"""
+    import torch
+    from movie_recommender_system_amd import engine as E, synth
+    U, I = 20_000, 700
+    M = synth.interactions(21, U, I, 30.0)
+    rs = np.random.RandomState(42)
+    F = E.factor_width(f)
+    X0 = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, F, dev)
+    Y0 = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, F, dev)
+    C = E.DeviceCSR.from_scipy(M, dev, scale=40.0)
+    G = E.gram(Y0, 0.01)
+    for cg_steps, short_max, chunk in ((-1, 0, E.auto_chunk(C.nnz)), (-1, 0, 32), (3, None, E.auto_chunk(C.nnz)), (3, 0, 64)):
+        plan = E.SweepPlan(C, F, chunk, short_max=short_max, conf_max=40.0)
+        ref = None
+        for _ in range(8):
+            X = X0.clone()
+            plan.sweep(X, Y0, G, cg_steps)
+            if ref is None:
+                ref = X
+                assert bool(torch.isfinite(X).all())
+            else:
+                differ = int((X != ref).any(dim=1).sum())
+                assert differ == 0, f"f={f} cg_steps={cg_steps} short_max={short_max} chunk={chunk}: {differ} rows changed"
