@@ -414,19 +414,36 @@ class AlternatingLeastSquares:
         u0, u1 = users if users is not None else (0, self.user_factors.shape[0])
         dev = E.require_cuda(self.device)
         with self._lock, torch.cuda.device(dev):
-            Yd = self._device_items(dev)
-            Q = E.pad_factors(self.user_factors[u0:u1], Yd.shape[1], dev)
+            st = self._serving_state(dev)          # both factor matrices stay on the device between calls
+            Yd = st.Y
+            Q = st.X[u0:u1]
             dmask = None
             if filter_already_liked_items:
-                if user_items is None:
-                    raise ValueError("user_items is needed to filter liked items")
-                m = sp.csr_matrix(user_items)[u0:u1]
-                if not m.has_sorted_indices:
-                    m = m.sorted_indices()
-                dmask = E.DeviceCSR.from_scipy(m, dev)
-            ids, scores = E.topk(Q, Yd, int(N), dmask)
-            ids = _hide_filtered(ids, scores, dmask)
-            return ids.cpu().numpy(), scores.cpu().numpy()
+                att = self._attached
+                if att is not None and (user_items is None or user_items is att[0]):
+                    d = att[1]                     # the attached matrix: its rows as a view, nothing uploaded
+                    dmask = E.DeviceCSR(d.indptr[u0:u1 + 1], d.indices, d.data, (u1 - u0, d.shape[1]))
+                else:
+                    if user_items is None:
+                        raise ValueError("user_items is needed to filter liked items")
+                    m = sp.csr_matrix(user_items)[u0:u1]
+                    if not m.has_sorted_indices:
+                        m = m.sorted_indices()
+                    dmask = E.DeviceCSR.from_scipy(m, dev)
+            n = Q.shape[0]
+            if n <= (1 << 17):
+                ids, scores = E.topk(Q, Yd, int(N), dmask)
+                ids = _hide_filtered(ids, scores, dmask)
+                return ids.cpu().numpy(), scores.cpu().numpy()
+            # many users: chunk by chunk, each chunk's download overlapping the next chunk's kernels
+            dl = E.ChunkedDownload(n, int(N), dev)
+            for a, b in dl.ranges():
+                # (the kernels index the filter's row pointers by query and read absolute offsets: a view will do)
+                m = None if dmask is None else E.DeviceCSR(dmask.indptr[a:b + 1], dmask.indices, dmask.data,
+                                                           (b - a, dmask.shape[1]))
+                ids, scores = E.topk(Q[a:b], Yd, int(N), m, path="sweep")
+                dl.submit(_hide_filtered(ids, scores, m), scores, a)
+            return dl.finish()
 
     def similar_items(self, itemid, N: int = 10, recalculate_item: bool = False, item_users=None,
                       filter_items=None, items=None):

@@ -80,7 +80,7 @@ class LightFMScorer:
     def _check_features(self, features: Optional[sp.spmatrix], n_rows_default: int, n_feat: int, what: str):
         if features is None:
             features = _identity(n_rows_default)
-        features = sp.csr_matrix(features).astype(np.float32)
+        features = sp.csr_matrix(features).astype(np.float32, copy=False)
         if features.shape[1] != n_feat:
             raise ValueError(f"The {what} feature matrix specifies {features.shape[1]} features, "
                              f"the model has {n_feat}")
@@ -203,8 +203,16 @@ class LightFMScorer:
             # operand rows [b_u, 1, e...] and [1, b_i, e...]: the MFMA chain then adds b_u, b_i, u_0 i_0, ...
             Q = self._repr(uf, t["ue"], t["ub"], self.user_scale, W, 2, 0, 1, dev)
             Y = self._repr(itf, t["ie"], t["ib"], self.item_scale, W, 2, 1, 0, dev)
-            ids, scores = E.topk(Q, Y, int(k))
-            return ids.cpu().numpy(), scores.cpu().numpy()
+            n = Q.shape[0]
+            if n <= (1 << 17):
+                ids, scores = E.topk(Q, Y, int(k))
+                return ids.cpu().numpy(), scores.cpu().numpy()
+            # many users: chunk by chunk, each chunk's download overlapping the next chunk's kernels
+            dl = E.ChunkedDownload(n, int(k), dev)
+            for a, b in dl.ranges():
+                ids, scores = E.topk(Q[a:b], Y, int(k), path="sweep")
+                dl.submit(ids, scores, a)
+            return dl.finish()
 
 
     # ---------------------------------------------------------- request path
