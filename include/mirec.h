@@ -55,9 +55,12 @@ int mirec_factor_width(int f, int for_scoring);
  * Replaces the `np.dot(Y.T, Y) + regularization * eye` that opens every
  * half-sweep of implicit's `_least_squares_cg`, reached from
  * als/als.py:174 and recommenders/als_recommender.py:136 (`model.fit`).
+ * `y_absmax` (one device float, may be null) receives the largest |entry| of Y,
+ * found on the same pass: mirec_als_half_sweep takes it beside G to scale the
+ * matrix-core operands of its explicit-Gram kernel.
  * `ws` must hold mirec_gram_workspace_bytes(n, f) bytes. */
 size_t mirec_gram_workspace_bytes(int64_t n, int f);
-int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, size_t ws_bytes,
+int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, float* y_absmax, void* ws, size_t ws_bytes,
                mirec_stream_t stream);
 
 /* mirec_gram without a workspace argument and without any allocation.  It has
@@ -71,9 +74,9 @@ int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, 
  * with MIREC_E_WORKSPACE (at f = 128: more than 131072 rows; at f <= 64 every
  * n fits).  All calls on one GPU share the buffer: calls that overlap there
  * (different streams or threads) race; calls on one stream are ordered. */
-#define MIREC_GRAM_STATIC_BYTES ((size_t)32 << 20)
+#define MIREC_GRAM_STATIC_BYTES (((size_t)32 << 20) + 4096)   /* 512 slots of 128 x 128 partial sums + one float each */
 size_t mirec_gram_static_max_bytes(void);
-int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, mirec_stream_t stream);
+int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, float* y_absmax, mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * ALS half-sweep (implicit `_least_squares_cg`, cg_steps = 3 by default):
@@ -106,11 +109,18 @@ int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, mir
  * `chunk_nnz` and `host_counts` exactly as the build left them and a workspace
  * of mirec_als_sweep_workspace_bytes(host_counts, f) bytes (needed whenever the
  * plan has chunks).
- *   G           must be the Gram of Y plus reg * I (mirec_gram): besides entering
- *               every A_u, its diagonal bounds the entries of Y, from which the
- *               explicit-Gram kernel takes the power of two that scales its fp16
- *               matrix-core operands (an entry of Y beyond sqrt(max G_jj) may
- *               overflow them)
+ *   G           must be the Gram of Y plus reg * I (mirec_gram)
+ *   y_absmax    one device float, the largest |entry| of Y as mirec_gram returns it,
+ *               or null.  The explicit-Gram kernel multiplies on the matrix cores:
+ *               every gathered row, scaled by sqrt(||c|-1|) and by one power of two
+ *               per launch, enters as two fp16 planes (22 significant bits where
+ *               fp32 has 24; sums and solves are fp32), and that power of two puts
+ *               y_absmax * sqrt(conf_max - 1) just below the fp16 maximum.  Null:
+ *               sqrt(max G_jj) stands in -- a bound of every |entry| that is up to the
+ *               square root of Y's row count too large, which costs no accuracy
+ *               until the confidences spread over more than about 2^10.  An entry
+ *               of Y beyond the value given (a y_absmax or G that belongs to another
+ *               matrix) overflows its operand and the row comes out non-finite.
  *   conf_max    the largest |c| over the stored entries -- of the whole matrix,
  *               so that every shard of a multi-GPU fit scales alike; an upper
  *               bound does; 0 = not known: the sweep then finds it with one pass
@@ -133,9 +143,9 @@ int mirec_als_plan_build(const int64_t* indptr, int64_t row_begin, int64_t row_e
                          int64_t host_counts[4], mirec_stream_t stream);
 size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], int f);
 int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
-                         int64_t row_end, int64_t nnz, float* X, const float* Y, int64_t y_rows, const float* G, int f,
-                         int cg_steps, const void* plan, int32_t chunk_nnz, int32_t short_max,
-                         const int64_t host_counts[4], float conf_max, void* ws, size_t ws_bytes,
+                         int64_t row_end, int64_t nnz, float* X, const float* Y, int64_t y_rows, const float* G,
+                         const float* y_absmax, int f, int cg_steps, const void* plan, int32_t chunk_nnz,
+                         int32_t short_max, const int64_t host_counts[4], float conf_max, void* ws, size_t ws_bytes,
                          mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -29,15 +29,15 @@ SIGNATURES = {
     "mirec_last_error": (_c.c_char_p, []),
     "mirec_factor_width": (_int, [_int, _int]),
     "mirec_gram_workspace_bytes": (_sz, [_i64, _int]),
-    "mirec_gram": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _sz, _vp]),
+    "mirec_gram": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _vp, _sz, _vp]),
     "mirec_gram_static_max_bytes": (_sz, []),
-    "mirec_gram_static": (_int, [_vp, _i64, _int, _f32, _vp, _vp]),
+    "mirec_gram_static": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _vp]),
     "mirec_als_plan_bytes": (_sz, [_i64, _i64, _i32]),
     "mirec_als_short_cache_rows": (_int, [_int]),
     "mirec_als_plan_build": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _sz, _c.POINTER(_i32), _i32,
                                     _c.POINTER(_i64), _vp]),
     "mirec_als_sweep_workspace_bytes": (_sz, [_c.POINTER(_i64), _int]),
-    "mirec_als_half_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _int, _int, _vp, _i32, _i32,
+    "mirec_als_half_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _int, _int, _vp, _i32, _i32,
                                     _c.POINTER(_i64), _f32, _vp, _sz, _vp]),
     "mirec_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mirec_csr_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -57,6 +57,8 @@ SIGNATURES = {
     "mirec_ranking_hits": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
 }
 
+ABI_VERSION = 102   # mirec_version() of the library these signatures belong to
+
 _lib = None
 _lock = threading.Lock()
 
@@ -75,6 +77,13 @@ def load(path: str = LIB_PATH):
                     f"{path} is missing: build it with `python __graft_entry__.py` "
                     "(hipcc --offload-arch=gfx950); there is no CPU fallback for the recommender core")
             lib = ctypes.CDLL(path)
+            lib.mirec_version.restype = _int
+            lib.mirec_version.argtypes = []
+            have = lib.mirec_version()
+            if have < ABI_VERSION:
+                # entry points have changed their parameters: an older build would be called with shifted arguments
+                raise MirecError(f"{path} is version {have}, this package binds version {ABI_VERSION}: rebuild it "
+                                 "with `python __graft_entry__.py`")
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype = res

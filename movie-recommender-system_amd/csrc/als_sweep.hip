@@ -578,12 +578,16 @@ __device__ __forceinline__ f32x4 mma3(f32x4 acc, const u32x4 (&l)[2], const u32x
     return acc;
 }
 
-// Power of two that puts the largest scaled entry z = sqrt(||c|-1|) y just below 2^15: |y| <= sqrt(gmax) for
-// gmax the largest diagonal entry of G = Y^T Y + reg I, ||c|-1| <= max(cmax - 1, 1).  Clamped to 2^+-40 so that
-// its inverse square stays a normal fp32 number.  Returns (scale, 1 / scale^2).
-__device__ __forceinline__ f32x2 gram_scale(float gmax, float cmax) {
+// Power of two that puts the largest scaled entry z = sqrt(||c|-1|) y just below 2^15: |y| <= ymax (the largest
+// |entry| of the gathered table where the caller has it, else sqrt of the largest diagonal entry of
+// G = Y^T Y + reg I, which bounds it but overshoots by up to the square root of the table's row count),
+// ||c|-1| <= max(cmax - 1, 1).  Clamped to 2^+-40 so that its inverse square stays a normal fp32 number.
+// Returns (scale, 1 / scale^2).  An entry keeps its 22 bits while |z| >= 2^-3, i.e. while
+// |y| sqrt(||c|-1|) is within 2^-18 of ymax sqrt(cmax - 1); below that the fp16 planes run out of exponent and
+// it keeps 2^-25 of the scale absolutely.
+__device__ __forceinline__ f32x2 gram_scale(float ymax, float cmax) {
     const float wmax = fmaxf(cmax - 1.f, 1.f);
-    const float bound = sqrtf(gmax) * sqrtf(wmax);
+    const float bound = ymax * sqrtf(wmax);
     int e = 0;
     (void)frexpf(bound, &e);  // bound = m 2^e, 0.5 <= m < 1 (e = 0 for bound = 0)
     int sh = 15 - e;
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     int64_t row_begin, float* X, const float* __restrict__ Y, const float* __restrict__ G,
     const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ mslot_ptr,
     const int32_t* __restrict__ chunk_row, int cg_steps, float* partials, float conf_max,
-    const float* __restrict__ conf_max_dev) {
+    const float* __restrict__ conf_max_dev, const float* __restrict__ y_absmax) {
     using C = GramCfg<NT>;
     constexpr int F = C::F;
     constexpr int NTHR = 128 * NT;
@@ -955,7 +959,7 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
         float gmax = vec[0];
 #pragma unroll
         for (int ww = 1; ww < 2 * NT; ++ww) gmax = fmaxf(gmax, vec[ww]);
-        sc = gram_scale(gmax, conf_max > 0.f ? conf_max : *conf_max_dev);
+        sc = gram_scale(y_absmax != nullptr ? *y_absmax : sqrtf(gmax), conf_max > 0.f ? conf_max : *conf_max_dev);
     }
     const float scale2 = sc[0] * sc[0], unscale = sc[1];
     constexpr int lda = EXACT ? C::LDX : F;
@@ -1078,7 +1082,7 @@ template <int NT, bool EXACT>
 static int launch_sweep_kind(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                              float* X, const float* Y, const float* G, int cg_steps, const char* plan,
                              const PlanLayout& L, const int64_t counts[3], float* partials, int64_t y_rows,
-                             float conf_max, const float* conf_max_dev, hipStream_t stream) {
+                             float conf_max, const float* conf_max_dev, const float* y_absmax, hipStream_t stream) {
     using S = GramCfg<NT>;
     const int32_t* chunk_ptr = (const int32_t*)(plan + L.chunk_ptr);
     const int32_t* mslot_ptr = (const int32_t*)(plan + L.mslot_ptr);
@@ -1102,11 +1106,11 @@ static int launch_sweep_kind(const int64_t* indptr, const int32_t* indices, cons
         if (big)
             hipLaunchKernelGGL((als_gram_cg_kernel<NT, true, EXACT>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
-                               cg_steps, partials, conf_max, conf_max_dev);
+                               cg_steps, partials, conf_max, conf_max_dev, y_absmax);
         else
             hipLaunchKernelGGL((als_gram_cg_kernel<NT, false, EXACT>), dim3((unsigned)counts[0]), dim3(128 * NT), S::BYTES,
                                stream, indptr, indices, data, row_begin, X, Y, G, chunk_ptr, mslot_ptr, chunk_row,
-                               cg_steps, partials, conf_max, conf_max_dev);
+                               cg_steps, partials, conf_max, conf_max_dev, y_absmax);
         MIREC_LAUNCH_CHECK();
     }
     if (counts[1] > 0) {
@@ -1121,13 +1125,14 @@ template <int NT>
 static int launch_sweep(const int64_t* indptr, const int32_t* indices, const float* data, int64_t row_begin,
                         float* X, const float* Y, const float* G, int cg_steps, const char* plan,
                         const PlanLayout& L, int32_t chunk_nnz, const int64_t counts[3], float* partials,
-                        int64_t y_rows, float conf_max, const float* conf_max_dev, hipStream_t stream) {
+                        int64_t y_rows, float conf_max, const float* conf_max_dev, const float* y_absmax,
+                        hipStream_t stream) {
     (void)chunk_nnz;
     if (cg_steps < 0)
         return launch_sweep_kind<NT, true>(indptr, indices, data, row_begin, X, Y, G, cg_steps, plan, L, counts,
-                                           partials, y_rows, conf_max, conf_max_dev, stream);
+                                           partials, y_rows, conf_max, conf_max_dev, y_absmax, stream);
     return launch_sweep_kind<NT, false>(indptr, indices, data, row_begin, X, Y, G, cg_steps, plan, L, counts, partials,
-                                        y_rows, conf_max, conf_max_dev, stream);
+                                        y_rows, conf_max, conf_max_dev, y_absmax, stream);
 }
 
 }  // namespace mirec
@@ -1225,9 +1230,10 @@ extern "C" size_t mirec_als_sweep_workspace_bytes(const int64_t host_counts[4], 
 
 extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indices, const float* data,
                                     int64_t row_begin, int64_t row_end, int64_t nnz, float* X, const float* Y,
-                                    int64_t y_rows, const float* G, int f, int cg_steps, const void* plan, int32_t chunk_nnz,
-                                    int32_t short_max, const int64_t host_counts[4], float conf_max, void* ws,
-                                    size_t ws_bytes, mirec_stream_t stream_) {
+                                    int64_t y_rows, const float* G, const float* y_absmax, int f, int cg_steps,
+                                    const void* plan, int32_t chunk_nnz, int32_t short_max,
+                                    const int64_t host_counts[4], float conf_max, void* ws, size_t ws_bytes,
+                                    mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (row_end == row_begin) return MIREC_OK;  // a shard without rows (its X block may be a null pointer)
     MIREC_REQUIRE(indptr && X && Y && G && plan && host_counts, MIREC_E_INVALID, "mirec_als_half_sweep: null argument");
@@ -1272,12 +1278,12 @@ extern "C" int mirec_als_half_sweep(const int64_t* indptr, const int32_t* indice
     }
     if (host_counts[0] == 0 && host_counts[1] == 0) return MIREC_OK;
     switch (f / 32) {
-        case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
-        case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
-        case 3: return launch_sweep<3>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
-        case 4: return launch_sweep<4>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
-        case 5: return launch_sweep<5>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
-        case 6: return launch_sweep<6>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, stream);
+        case 1: return launch_sweep<1>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, y_absmax, stream);
+        case 2: return launch_sweep<2>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, y_absmax, stream);
+        case 3: return launch_sweep<3>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, y_absmax, stream);
+        case 4: return launch_sweep<4>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, y_absmax, stream);
+        case 5: return launch_sweep<5>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, y_absmax, stream);
+        case 6: return launch_sweep<6>(indptr, indices, data, row_begin, X, Y, G, cg_steps, p, L, chunk_nnz, host_counts, partials, y_rows, conf_max, conf_max_dev, y_absmax, stream);
     }
     return MIREC_E_UNSUPPORTED;
 }

@@ -14,7 +14,9 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace mirec
 
-extern "C" int mirec_version(void) { return 101; }  // 101: cg_steps = MIREC_SOLVE_EXACT
+// 101: cg_steps = MIREC_SOLVE_EXACT (and conf_max in mirec_als_half_sweep: a change of signature)
+// 102: y_absmax in mirec_gram, mirec_gram_static and mirec_als_half_sweep (a change of signature); mirec_topk_small
+extern "C" int mirec_version(void) { return 102; }
 
 extern "C" const char* mirec_last_error(void) { return mirec::g_error; }
 

@@ -30,9 +30,10 @@ struct GramWaves {
 };
 
 // Wave role W of a group: band-rows W and R1 = NT-1-W (the same one when NT is odd and W is the middle).
+// (role 0 loads every column band of its rows, so it also keeps the largest |entry| it sees: `amax`)
 template <int NT, int W>
 __device__ __forceinline__ void gram_rows_wave(const float* __restrict__ Y, int64_t r0, int64_t r1, float* out,
-                                               int lane) {
+                                               int lane, float* amax) {
     constexpr int F = 32 * NT;
     constexpr int R1 = NT - 1 - W;
     constexpr int N0 = NT - W;                  // tiles (W, W..NT-1)
@@ -67,8 +68,15 @@ __device__ __forceinline__ void gram_rows_wave(const float* __restrict__ Y, int6
         }
     };
     if (r0 < r1) load(cur, r0);
+    float big = 0.f;
     for (int64_t r = r0; r < r1; r += 8) {
         if (r + 8 < r1) load(nxt, r + 8);
+        if constexpr (W == 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int t = 0; t < N0; ++t) big = fmaxf(big, fabsf(cur[p][t]));  // (fmaxf drops a NaN operand)
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
 #pragma unroll
@@ -84,6 +92,11 @@ __device__ __forceinline__ void gram_rows_wave(const float* __restrict__ Y, int6
             for (int t = 0; t < N0; ++t) cur[p][t] = nxt[p][t];
     }
 
+    if constexpr (W == 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) big = fmaxf(big, __shfl_xor(big, off, 64));
+        if (lane == 0) *amax = big;
+    }
 #pragma unroll
     for (int t = 0; t < N0; ++t)
 #pragma unroll
@@ -104,7 +117,8 @@ __device__ __forceinline__ void gram_rows_wave(const float* __restrict__ Y, int6
 template <int NT>
 __global__ __launch_bounds__(64 * GramWaves<NT>::NW) void gram_partial_kernel(const float* __restrict__ Y, int64_t n,
                                                                               int rows_per_block,
-                                                                              float* __restrict__ partials) {
+                                                                              float* __restrict__ partials,
+                                                                              float* __restrict__ slot_max) {
     constexpr int F = 32 * NT;
     constexpr int ROLES = GramWaves<NT>::ROLES;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -117,18 +131,29 @@ __global__ __launch_bounds__(64 * GramWaves<NT>::NW) void gram_partial_kernel(co
     if (r0 > n) r0 = n;
     if (r1 > n) r1 = n;
     float* out = partials + ((size_t)blockIdx.x * GRAM_GROUPS + group) * F * F;
+    float* amax = slot_max + (size_t)blockIdx.x * GRAM_GROUPS + group;
     switch (role) {
-        case 0: gram_rows_wave<NT, 0>(Y, r0, r1, out, lane); break;
-        case 1: if constexpr (ROLES > 1) gram_rows_wave<NT, 1>(Y, r0, r1, out, lane); break;
-        case 2: if constexpr (ROLES > 2) gram_rows_wave<NT, 2>(Y, r0, r1, out, lane); break;
+        case 0: gram_rows_wave<NT, 0>(Y, r0, r1, out, lane, amax); break;
+        case 1: if constexpr (ROLES > 1) gram_rows_wave<NT, 1>(Y, r0, r1, out, lane, amax); break;
+        case 2: if constexpr (ROLES > 2) gram_rows_wave<NT, 2>(Y, r0, r1, out, lane, amax); break;
     }
 }
 
 // One workgroup per 64 elements of the upper block triangle; four threads share the slots of an element
 // (slot s goes to thread s & 3) and their fp64 sums are combined in a fixed order.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ partials, int nslots, int f,
-                                                          float reg, float* __restrict__ G) {
+                                                          float reg, float* __restrict__ G,
+                                                          const float* __restrict__ slot_max,
+                                                          float* __restrict__ y_absmax) {
     __shared__ double part[4][64];
+    if (y_absmax != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
+        // the largest |entry| of the matrix: the maximum of the slots' (wavefront 0 of the first workgroup)
+        float m = 0.f;
+        for (int b = threadIdx.x; b < nslots; b += 64) m = fmaxf(m, slot_max[b]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (threadIdx.x == 0) *y_absmax = m;
+    }
     const int ff = f * f;
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     const int q = threadIdx.x >> 6;
@@ -150,17 +175,20 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
 }
 
 template <int NT>
-static int launch_gram(const float* Y, int64_t n, float reg, float* G, float* partials, hipStream_t stream) {
+static int launch_gram(const float* Y, int64_t n, float reg, float* G, float* y_absmax, float* partials,
+                       hipStream_t stream) {
     constexpr int F = 32 * NT;
     const int rpb = gram_rows_per_block(n);
     const int nblk = (int)((n + rpb - 1) / rpb);
+    // the slots' largest magnitudes follow the slots in the workspace
+    float* slot_max = partials + (size_t)(nblk > 0 ? nblk : 1) * GRAM_GROUPS * F * F;
     if (nblk > 0) {
         hipLaunchKernelGGL(gram_partial_kernel<NT>, dim3(nblk), dim3(64 * GramWaves<NT>::NW), 0, stream, Y, n, rpb,
-                           partials);
+                           partials, slot_max);
         MIREC_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((F * F + 63) / 64), dim3(256), 0, stream, partials,
-                       nblk * GRAM_GROUPS, F, reg, G);
+                       nblk * GRAM_GROUPS, F, reg, G, slot_max, y_absmax);
     MIREC_LAUNCH_CHECK();
     return MIREC_OK;
 }
@@ -195,14 +223,15 @@ static float* static_scratch() {
     return scratch_of[d];
 }
 
-static int gram_dispatch(const float* Y, int64_t n, int f, float reg, float* G, float* partials, hipStream_t stream) {
+static int gram_dispatch(const float* Y, int64_t n, int f, float reg, float* G, float* y_absmax, float* partials,
+                         hipStream_t stream) {
     switch (f / 32) {
-        case 1: return launch_gram<1>(Y, n, reg, G, partials, stream);
-        case 2: return launch_gram<2>(Y, n, reg, G, partials, stream);
-        case 3: return launch_gram<3>(Y, n, reg, G, partials, stream);
-        case 4: return launch_gram<4>(Y, n, reg, G, partials, stream);
-        case 5: return launch_gram<5>(Y, n, reg, G, partials, stream);
-        case 6: return launch_gram<6>(Y, n, reg, G, partials, stream);
+        case 1: return launch_gram<1>(Y, n, reg, G, y_absmax, partials, stream);
+        case 2: return launch_gram<2>(Y, n, reg, G, y_absmax, partials, stream);
+        case 3: return launch_gram<3>(Y, n, reg, G, y_absmax, partials, stream);
+        case 4: return launch_gram<4>(Y, n, reg, G, y_absmax, partials, stream);
+        case 5: return launch_gram<5>(Y, n, reg, G, y_absmax, partials, stream);
+        case 6: return launch_gram<6>(Y, n, reg, G, y_absmax, partials, stream);
     }
     return MIREC_E_UNSUPPORTED;
 }
@@ -213,11 +242,12 @@ extern "C" size_t mirec_gram_workspace_bytes(int64_t n, int f) {
     if (n < 0 || f <= 0) return 0;
     const int rpb = mirec::gram_rows_per_block(n);
     const int64_t nblk = (n + rpb - 1) / rpb;
-    return (size_t)(nblk > 0 ? nblk : 1) * mirec::GRAM_GROUPS * f * f * sizeof(float);
+    // per slot: F x F partial sums and one float, the slot's largest |entry|
+    return (size_t)(nblk > 0 ? nblk : 1) * mirec::GRAM_GROUPS * ((size_t)f * f + 1) * sizeof(float);
 }
 
-extern "C" int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, void* ws, size_t ws_bytes,
-                          mirec_stream_t stream_) {
+extern "C" int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G, float* y_absmax, void* ws,
+                          size_t ws_bytes, mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MIREC_REQUIRE(G != nullptr && n >= 0, MIREC_E_INVALID, "mirec_gram: null output or negative n");
     MIREC_REQUIRE(n == 0 || Y != nullptr, MIREC_E_INVALID, "mirec_gram: null input");
@@ -225,12 +255,13 @@ extern "C" int mirec_gram(const float* Y, int64_t n, int f, float reg, float* G,
                   "mirec_gram: factor width %d is not a multiple of 32 in [32,192]; zero-pad the columns", f);
     MIREC_REQUIRE(ws != nullptr && ws_bytes >= mirec_gram_workspace_bytes(n, f), MIREC_E_WORKSPACE,
                   "mirec_gram: workspace of %zu bytes needed, %zu given", mirec_gram_workspace_bytes(n, f), ws_bytes);
-    return mirec::gram_dispatch(Y, n, f, reg, G, (float*)ws, stream);
+    return mirec::gram_dispatch(Y, n, f, reg, G, y_absmax, (float*)ws, stream);
 }
 
 extern "C" size_t mirec_gram_static_max_bytes(void) { return mirec::GRAM_STATIC_BYTES; }
 
-extern "C" int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, mirec_stream_t stream_) {
+extern "C" int mirec_gram_static(const float* Y, int64_t n, int f, float reg, float* G, float* y_absmax,
+                                 mirec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MIREC_REQUIRE(G != nullptr && n >= 0, MIREC_E_INVALID, "mirec_gram_static: null output or negative n");
     MIREC_REQUIRE(n == 0 || Y != nullptr, MIREC_E_INVALID, "mirec_gram_static: null input");
@@ -243,6 +274,7 @@ extern "C" int mirec_gram_static(const float* Y, int64_t n, int f, float reg, fl
                   mirec::GRAM_STATIC_BYTES);
     float* partials = mirec::static_scratch();
     if (partials == nullptr) return MIREC_E_HIP;
-    // Nothing has to start at zero: the partial kernel writes every element of the slots the reduction reads.
-    return mirec::gram_dispatch(Y, n, f, reg, G, partials, stream);
+    // Nothing has to start at zero: the partial kernel writes every element of the slots (and every slot maximum)
+    // the reduction reads.
+    return mirec::gram_dispatch(Y, n, f, reg, G, y_absmax, partials, stream);
 }

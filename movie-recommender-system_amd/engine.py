@@ -141,8 +141,10 @@ class DeviceCSR:
                              shape=self.shape)
 
 
-def gram(Y: torch.Tensor, reg: float, out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
-    """G = Y^T Y + reg I for a padded device factor matrix."""
+def gram(Y: torch.Tensor, reg: float, out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+         absmax: Optional[torch.Tensor] = None):
+    """G = Y^T Y + reg I for a padded device factor matrix; ``absmax`` (one device float) receives the largest
+    |entry| of Y, found on the same pass."""
     lib = _lib.require()
     n, f = Y.shape
     need = lib.mirec_gram_workspace_bytes(n, f)
@@ -150,7 +152,8 @@ def gram(Y: torch.Tensor, reg: float, out: Optional[torch.Tensor] = None, ws: Op
         ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=Y.device)
     if out is None:
         out = torch.empty((f, f), dtype=torch.float32, device=Y.device)
-    _lib.check(lib.mirec_gram(_ptr(Y), n, f, float(reg), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), "mirec_gram")
+    _lib.check(lib.mirec_gram(_ptr(Y), n, f, float(reg), _ptr(out), _ptr(absmax), _ptr(ws), ws.numel(), _stream_ptr()),
+               "mirec_gram")
     return out
 
 
@@ -220,14 +223,16 @@ class SweepPlan:
         return int(self.counts[3])
 
     def sweep(self, X_rows: torch.Tensor, Y: torch.Tensor, G: torch.Tensor, cg_steps: int = 3,
-              phase: str = "both", y_rows: Optional[int] = None) -> None:
+              phase: str = "both", y_rows: Optional[int] = None, y_absmax: Optional[torch.Tensor] = None) -> None:
         """Solve the plan's rows in place: ``X_rows`` is the [nrows, f] block of
         the factor matrix that belongs to these CSR rows.  ``phase`` lets a
         profiler bracket the kernels of a sweep separately: "short" launches
         only the matrix-free kernel, "main" only the Gram+CG kernel, "finalize"
         only the split-row reduction (which must follow "main" on the stream).
         ``y_rows`` overrides the row count of ``Y`` passed to the library (0 =
-        "not known", which selects 64-bit addressing of the gathered table)."""
+        "not known", which selects 64-bit addressing of the gathered table).
+        ``y_absmax``: the largest |entry| of ``Y`` as ``gram`` returns it (one
+        device float; None: the library bounds it from the diagonal of G)."""
         lib = _lib.require()
         csr = self.csr
         assert X_rows.shape == (csr.shape[0], self.f) and X_rows.is_contiguous()
@@ -240,7 +245,8 @@ class SweepPlan:
             if phase != "short":
                 short_max = -1
         _lib.check(lib.mirec_als_half_sweep(_ptr(csr.indptr), _ptr(csr.indices), _ptr(csr.data), 0, csr.shape[0],
-                                            csr.nnz, _ptr(X_rows), _ptr(Y), int(Y.shape[0] if y_rows is None else y_rows), _ptr(G), self.f, int(cg_steps),
+                                            csr.nnz, _ptr(X_rows), _ptr(Y), int(Y.shape[0] if y_rows is None else y_rows), _ptr(G),
+                                            _ptr(y_absmax), self.f, int(cg_steps),
                                             _ptr(self.plan), self.chunk_nnz, short_max, counts, self.conf_max,
                                             _ptr(self.ws), self.ws.numel(), _stream_ptr()), "mirec_als_half_sweep")
 
@@ -293,6 +299,7 @@ class AlsEngine:
         need = max(lib.mirec_gram_workspace_bytes(users, self.f), lib.mirec_gram_workspace_bytes(items, self.f))
         self.gram_ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=X.device)
         self.G = torch.empty((self.f, self.f), dtype=torch.float32, device=X.device)
+        self.absmax = torch.zeros(1, dtype=torch.float32, device=X.device)   # largest |entry| of the table G is the Gram of
 
     # Every launch goes through _run so that a benchmark can bracket each kernel
     # with events on the launching stream (self.events = [] switches it on).
@@ -310,14 +317,14 @@ class AlsEngine:
 
     def _sweep(self, tag: str, plan: "SweepPlan", rows: torch.Tensor, other: torch.Tensor) -> None:
         if self.events is None:
-            plan.sweep(rows, other, self.G, self.cg_steps)
+            plan.sweep(rows, other, self.G, self.cg_steps, y_absmax=self.absmax)
             return
         if plan.n_short_rows:
-            self._run(tag + "_short", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "short"))
+            self._run(tag + "_short", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "short", y_absmax=self.absmax))
         if plan.n_chunks:
-            self._run(tag + "_main", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "main"))
+            self._run(tag + "_main", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "main", y_absmax=self.absmax))
         if plan.n_split_rows:
-            self._run(tag + "_finalize", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "finalize"))
+            self._run(tag + "_finalize", lambda: plan.sweep(rows, other, self.G, self.cg_steps, "finalize", y_absmax=self.absmax))
 
     @property
     def plan_u(self) -> "SweepPlan":
@@ -340,7 +347,7 @@ class AlsEngine:
     def user_sweep_block(self, j: int) -> None:
         """Solve user block j; block 0 first refreshes the Gram of Y."""
         if j == 0:
-            self._run("gram_items", lambda: gram(self.Y, self.reg, self.G, self.gram_ws))
+            self._run("gram_items", lambda: gram(self.Y, self.reg, self.G, self.gram_ws, self.absmax))
         plan = self.plans_u[j]
         if plan is not None:
             u0, u1 = self.user_blocks[j]
@@ -351,7 +358,7 @@ class AlsEngine:
             self.user_sweep_block(j)
 
     def item_sweep(self) -> None:
-        self._run("gram_users", lambda: gram(self.X, self.reg, self.G, self.gram_ws))
+        self._run("gram_users", lambda: gram(self.X, self.reg, self.G, self.gram_ws, self.absmax))
         i0, i1 = self.item_rows
         self._sweep("item", self.plan_i, self.Y[i0:i1], self.X)
 

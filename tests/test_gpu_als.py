@@ -96,6 +96,51 @@ def test_half_sweep_matches_oracle(dev, f, chunk, short_max):
     assert np.array_equal(dX3.cpu().numpy(), out)
 
 
+def test_explicit_gram_keeps_its_bits_with_an_outlier_confidence_and_a_large_table(dev):
+    """The explicit-Gram kernel feeds the matrix cores two fp16 planes per operand under ONE power-of-two scale per
+    launch, fixed by the largest |entry| of the gathered table times sqrt(largest confidence - 1).  One confidence
+    of 1e9 among confidences of 2, and a table of 200 000 rows whose Gram diagonal overshoots the largest entry
+    a hundredfold: the rows that do not hold the outlier must still be solved to fp32 accuracy, with the table's
+    true largest magnitude (what `gram` returns beside G) and with the looser bound from the diagonal of G that
+    stands in when the caller has no such value.  (Measured: 2.5e-7 both ways -- where the diagonal bound is
+    loose the table is large and its Gram dominates every row's system, so the bits the small operands lose do
+    not show.)  Judged against a float64 solve of every row's normal equations (exact solver: no CG chaos)."""
+    import torch
+    from movie_recommender_system_amd import engine as E
+    rng = np.random.default_rng(77)
+    rows, cols, f = 400, 200_000, 64
+    Y = (rng.standard_normal((cols, f)) * 0.1).astype(np.float32)
+    deg = 70
+    idx = np.sort(np.stack([rng.choice(cols, deg, replace=False) for _ in range(rows)]), axis=1)
+    data = np.full((rows, deg), 2.0, dtype=np.float32)
+    data[7, 3] = 1e9                                    # the outlier: one entry of one row
+    C = sp.csr_matrix((data.ravel(), idx.ravel(), np.arange(0, rows * deg + 1, deg)), shape=(rows, cols))
+    dC = E.DeviceCSR.from_scipy(C, dev)
+    dY = torch.from_numpy(Y).to(dev)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    G = E.gram(dY, 0.01, absmax=amax)
+    assert float(amax) == float(np.abs(Y).max())
+    assert float(torch.sqrt(G.diagonal().max())) > 50 * float(amax)      # the diagonal bound is far off here
+    Y64 = Y.astype(np.float64)
+    G64 = Y64.T @ Y64 + 0.01 * np.eye(f)
+    want = np.zeros((rows, f))
+    for r in range(rows):
+        yk, c = Y64[idx[r]], data[r].astype(np.float64)
+        A = G64 + (yk.T * (c - 1.0)) @ yk
+        want[r] = np.linalg.solve(A, yk.T @ c)
+    plan = E.SweepPlan(dC, f, 0, short_max=0, conf_max=1e9)
+    normal = np.arange(rows) != 7
+    errs = {}
+    for name, bound in (("true largest magnitude", amax), ("diagonal of G", None)):
+        X = torch.zeros((rows, f), dtype=torch.float32, device=dev)
+        plan.sweep(X, dY, G, -1, y_absmax=bound)
+        got = X.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), name
+        errs[name] = float(np.linalg.norm(got[normal] - want[normal]) / np.linalg.norm(want[normal]))
+    print("relative error of the rows without the outlier:", errs)
+    assert errs["true largest magnitude"] < 3e-6 and errs["diagonal of G"] < 3e-6
+
+
 def _posv_f32(C, Y, reg):
     """The exact solve the way implicit's `_least_squares` does it: LAPACK sposv on the fp32 system of every row
     (scipy's assume_a="pos" solver is that routine).  The systems are accumulated in fp64 and rounded once."""

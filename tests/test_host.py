@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.mirec_version() >= 100
+    assert lib.mirec_version() >= _lib.ABI_VERSION == 102
     assert lib.mirec_factor_width(2, 0) == 32 and lib.mirec_factor_width(100, 0) == 128
     assert lib.mirec_factor_width(17, 1) == 24 and lib.mirec_factor_width(193, 0) == -1
     assert lib.mirec_als_short_cache_rows(128) >= 8 and lib.mirec_als_short_cache_rows(128) % 2 == 0
@@ -42,7 +42,7 @@ def test_abi_rejects_bad_arguments_without_touching_a_device():
     assert rc == -1 and "k must be" in _lib.last_error()
     rc = lib.mirec_topk(None, 4, None, 4, 20, None, None, None, None, 500, None, None, None, 0, None)
     assert rc == -4 and "224" in _lib.last_error()
-    rc = lib.mirec_gram(None, 10, 50, 0.1, None, None, 0, None)
+    rc = lib.mirec_gram(None, 10, 50, 0.1, None, None, None, 0, None)
     assert rc != 0
     with pytest.raises(_lib.MirecError):
         _lib.check(rc, "mirec_gram")

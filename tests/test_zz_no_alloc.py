@@ -21,9 +21,10 @@ def test_gram_static_matches_gram_with_workspace():
     dev = torch.device("cuda", 0)
     lib = _lib.require()
     cap = int(lib.mirec_gram_static_max_bytes())
-    assert cap == 32 << 20
+    assert cap == (32 << 20) + 4096
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(5)
+    warmed = [False]
 
     def both(n, f, reg):
         Y = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)
@@ -32,13 +33,24 @@ def test_gram_static_matches_gram_with_workspace():
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
         G_ws = torch.full((f, f), float("nan"), dtype=torch.float32, device=dev)
         G_st = torch.full((f, f), float("nan"), dtype=torch.float32, device=dev)
-        _lib.check(lib.mirec_gram(_ptr(Y), n, f, reg, _ptr(G_ws), _ptr(ws), need, stream), "mirec_gram")
+        m_ws = torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
+        m_st = torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
+        _lib.check(lib.mirec_gram(_ptr(Y), n, f, reg, _ptr(G_ws), _ptr(m_ws), _ptr(ws), need, stream), "mirec_gram")
+        torch.cuda.synchronize()
+        # what the driver reports as free device memory (hipMemGetInfo) sees any allocation, the library's own
+        # included -- torch's counters would only see torch's
+        free_before = torch.cuda.mem_get_info(dev)[0]
         before = torch.cuda.memory_allocated(dev)
-        _lib.check(lib.mirec_gram_static(_ptr(Y), n, f, reg, _ptr(G_st), stream), "mirec_gram_static")
+        _lib.check(lib.mirec_gram_static(_ptr(Y), n, f, reg, _ptr(G_st), _ptr(m_st), stream), "mirec_gram_static")
         torch.cuda.synchronize()
         assert torch.cuda.memory_allocated(dev) == before
+        if warmed[0]:      # (the first call on a device loads the kernels' code object)
+            assert torch.cuda.mem_get_info(dev)[0] == free_before, "the entry point changed the free device memory"
+        warmed[0] = True
         a, b = G_ws.cpu().numpy(), G_st.cpu().numpy()
         assert np.isfinite(a).all() and np.array_equal(a, b), f"n={n} f={f}: results differ"
+        want = float(Y.abs().max()) if n else 0.0
+        assert float(m_ws) == want and float(m_st) == want, f"n={n} f={f}: largest magnitude {float(m_ws)}, {float(m_st)} != {want}"
         ref = Y.cpu().numpy().astype(np.float64)
         ref = ref.T @ ref + reg * np.eye(f)
         assert np.abs(b - ref).max() <= 1e-5 * np.abs(ref).max()
@@ -59,7 +71,7 @@ def test_gram_static_matches_gram_with_workspace():
     assert int(lib.mirec_gram_workspace_bytes(n_big, 128)) > cap
     Y = torch.zeros((n_big, 128), dtype=torch.float32, device=dev)
     G = torch.zeros((128, 128), dtype=torch.float32, device=dev)
-    rc = lib.mirec_gram_static(_ptr(Y), n_big, 128, 0.01, _ptr(G), stream)
+    rc = lib.mirec_gram_static(_ptr(Y), n_big, 128, 0.01, _ptr(G), None, stream)
     assert rc == -2 and "static" in _lib.last_error()
     with pytest.raises(_lib.MirecError):
-        _lib.check(lib.mirec_gram_static(_ptr(Y), 10, 100, 0.01, _ptr(G), stream), "mirec_gram_static")
+        _lib.check(lib.mirec_gram_static(_ptr(Y), 10, 100, 0.01, _ptr(G), None, stream), "mirec_gram_static")
