@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--no-lightfm", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the factors=64 figures beside the headline")
     ap.add_argument("--no-requests", action="store_true", help="skip the per-request latency figures")
+    ap.add_argument("--no-matrix-build", action="store_true", help="skip the events -> CSR figures")
     return ap.parse_args()
 
 
@@ -258,6 +259,54 @@ def request_latency(dev, X, Y, f, liked_dev, items, seed, calls=2000):
         del sc, state, prob
     torch.cuda.synchronize()
     return out
+
+
+def matrix_build(dev, csr, U, I, seed):
+    """The step before the path (`build_matrix`, als/als.py:107-123: a pandas groupby over the watch events, then
+    scipy's CSR constructor): the benchmark matrix's pairs, a tenth of them seen twice, in random order, turned
+    into the binary CSR and the per-movie counts by `mirec_events_to_csr`; beside it the reference's own host
+    statements on a sample of the same events, scaled by the event count."""
+    import pandas as pd
+    import scipy.sparse as sp
+    import torch
+    from movie_recommender_system_amd import engine as E
+
+    rows = torch.repeat_interleave(torch.arange(U, dtype=torch.int32, device=dev), (csr.indptr[1:] - csr.indptr[:-1]))
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    again = torch.randint(0, rows.numel(), (rows.numel() // 10,), device=dev, generator=g)
+    eu, ei = torch.cat([rows, rows[again]]), torch.cat([csr.indices, csr.indices[again]])
+    perm = torch.randperm(eu.numel(), device=dev, generator=g)
+    eu, ei = eu[perm].contiguous(), ei[perm].contiguous()
+    del rows, again, perm
+    n = int(eu.numel())
+    E.DeviceCSR.from_events(eu[:1 << 20].contiguous(), ei[:1 << 20].contiguous(), (U, I), with_item_counts=True)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out, counts = E.DeviceCSR.from_events(eu, ei, (U, I), with_item_counts=True)
+        b.record()
+        torch.cuda.synchronize()
+        best = a.elapsed_time(b) if best is None else min(best, a.elapsed_time(b))
+    assert out.nnz == csr.nnz
+    # events in (8 B each), CSR out (index + value per pair, row pointers), counts: what any build must move
+    moved = n * 8.0 + out.nnz * 8.0 + (U + 1) * 8.0 + I * 4.0
+    ns = min(n, 5_000_000)
+    hu, hi = eu[:ns].cpu().numpy(), ei[:ns].cpu().numpy()
+    t0 = time.perf_counter()
+    df = pd.DataFrame({"user_idx": hu, "movie_idx": hi})
+    grouped = df.groupby(["user_idx", "movie_idx"]).size().reset_index(name="count")       # als/als.py:118
+    m = sp.csr_matrix((np.ones(len(grouped), dtype=np.float32), (grouped["user_idx"].to_numpy(), grouped["movie_idx"].to_numpy())),
+                      shape=(U, I))                                                        # als/als.py:119-122
+    t_host = time.perf_counter() - t0
+    del m, df, grouped
+    return {"events": n, "pairs": int(out.nnz), "device_ms": best, "events_per_s": n / (best * 1e-3),
+            "compulsory_GBps": moved / (best * 1e-3) / 1e9,
+            "host_pandas_groupby_and_scipy": {"sample_events": ns, "seconds": t_host, "events_per_s": ns / t_host,
+                                              "scaled_to_all_events_s": t_host * n / ns},
+            "speedup_vs_host": (t_host * n / ns) / (best * 1e-3)}
 
 
 def main():
@@ -568,6 +617,8 @@ def main():
         extra["cpu_oracle_other_passes"] = cpu_side_baselines(Cu0, I, f, args.topk, args.seed)
         if not args.no_requests:
             extra["request_latency"] = request_latency(dev, X, Y, f, Cu0, I, args.seed)
+        if not args.no_matrix_build and nnz < 400_000_000:
+            extra["matrix_build"] = matrix_build(dev, Cu0, U, I, args.seed)
         if f != 64 and not args.no_config1:
             # BASELINE configs[0]: the same matrix at factors = 64 -- the CPU oracle on a bounded sample and the
             # device iteration beside it (same shards and plans' policy, factor width 64)

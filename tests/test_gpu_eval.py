@@ -72,6 +72,35 @@ def test_events_to_csr_matches_host_build(dev, n_events, nu, ni):
     assert np.array_equal(counts.cpu().numpy(), np.asarray(ref.sum(axis=0)).ravel().astype(np.int32))
 
 
+@pytest.mark.timeout(900)
+def test_events_to_csr_at_the_scale_that_motivates_it(dev):
+    """5.3e7 watch events of 1 M users x 27 k movies (the benchmark matrix's 4.8e7 pairs, a tenth of them seen
+    twice, in random order): the device build gives the arrays scipy's `sum_duplicates` gives on the host."""
+    import torch
+    from movie_recommender_system_amd import engine as E, synth
+    U, I = 1_000_000, 27_000
+    indptr, indices, _ = synth.interactions_torch(42, U, I, 50.0, dev)
+    rows = torch.repeat_interleave(torch.arange(U, dtype=torch.int32, device=dev), (indptr[1:] - indptr[:-1]))
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    again = torch.randint(0, rows.numel(), (rows.numel() // 10,), device=dev, generator=g)
+    eu, ei = torch.cat([rows, rows[again]]), torch.cat([indices, indices[again]])
+    perm = torch.randperm(eu.numel(), device=dev, generator=g)
+    eu, ei = eu[perm].contiguous(), ei[perm].contiguous()
+    del rows, again, perm
+    assert eu.numel() > 52_000_000
+    csr, counts = E.DeviceCSR.from_events(eu, ei, (U, I), with_item_counts=True)
+    assert csr.nnz == indices.numel()
+    assert torch.equal(csr.indptr, indptr) and torch.equal(csr.indices, indices) and bool((csr.data == 1.0).all())
+    # the host's answer from the same events (scipy; ~10 s)
+    ref = sp.csr_matrix((np.ones(eu.numel(), dtype=np.float32), (eu.cpu().numpy(), ei.cpu().numpy())), shape=(U, I))
+    ref.sum_duplicates()
+    ref.sort_indices()
+    assert ref.nnz == csr.nnz
+    assert np.array_equal(ref.indptr, csr.indptr.cpu().numpy()) and np.array_equal(ref.indices, csr.indices.cpu().numpy())
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(ref.indices, minlength=I).astype(np.int32))
+
+
 def test_build_matrix_device_keeps_the_string_order_contract(dev):
     from movie_recommender_system_amd import artifacts
     users = [10, 9, 10, "a", 9, 10, 2, "10"]
