@@ -38,6 +38,8 @@ VERBOSE = False
 DEGENERATE = []  # the same, in systems with fewer gathered rows than f / 3, beyond 20x the measured sensitivity
 DEGENERATE_FACTOR = 100.0  # ... which must still end this close (squared A-norm error) to where the oracle ends
 SENSITIVE = []   # sweep cases beyond 2e-5 of the oracle that the float64 statement shows to be rounding-sensitive
+                 # (rows with fewer stored entries than f only)
+FULL_RANK_BEYOND = []  # sweep cases in which a row with >= f stored entries missed 2e-5 (judged by float64 arbitration)
 
 
 def rand_liked(rng, nq, ni, style):
@@ -190,14 +192,33 @@ def case_sweep(rng):
         Y64 = Y.astype(np.float64)
         G64 = Y64.T @ Y64 + reg * np.eye(f)
         bad = []
-        for r in np.nonzero(rd > 2e-5 * scale)[0]:
+        ln = np.diff(m.indptr)
+        beyond = np.nonzero(rd > 2e-5 * scale)[0]
+        # Rows with at least f stored entries have a full-rank system (the catalogue then has f items or more, so
+        # G alone is positive definite well above reg): nothing chaotic about three CG steps there, and such a row
+        # may miss the tolerance only where the ORACLE's own fp32 rounding is what separates the two -- the float64
+        # statement arbitrates: the device must not be further from it than 1.5x the oracle is.
+        full = [int(r) for r in beyond if ln[r] >= f]
+        for r in full:
+            if rd[r] > 1.5 * ro[r] + 2e-5 * scale[r]:
+                print(f"FAIL {desc}: row {r} with {ln[r]} >= f entries is {rd[r]:.3e} from float64, the oracle "
+                      f"{ro[r]:.3e}", flush=True)
+                ok = False
+        if full:
+            FULL_RANK_BEYOND.append((desc, len(full), float(max(rd[r] / max(ro[r], 1e-30) for r in full))))
+        for r in beyond:
+            if ln[r] >= f:
+                continue
             A, b = als_numpy.row_system(m, int(r), Y64, G64)
             sens = max(float(np.linalg.norm(cg_steps_f32(A, b, X[r], 3, order) - X64[r]))
                        for order in (None, 1, 2, 3))
             if rd[r] > 20.0 * max(sens, ro[r]) + 2e-5 * scale[r]:
                 bad.append((int(r), sens))
-        if not bad:
-            SENSITIVE.append((desc, err, float(rd.max()), float(ro.max())))
+        if not ok:
+            pass
+        elif not bad:
+            if len(full) < len(beyond):
+                SENSITIVE.append((desc, err, float(rd.max()), float(ro.max())))
         elif 3 * cols <= f:
             # reg*I plus a part of rank well below f: four summation orders do not bound the tail of a chaotic
             # iterate (single rows of such systems were seen 25x apart between two numpy orders, and the oracle
@@ -222,8 +243,20 @@ def case_sweep(rng):
                     measure = lambda x: float(np.linalg.norm(b - A @ x) ** 2)
                 ref = max([measure(Xo[r].astype(np.float64))] +
                           [measure(cg_steps_f32(A, b, X[r], 3, order).astype(np.float64)) for order in (None, 1, 2, 3)])
+                # ... and of the model of what the explicit-Gram kernel computes: exact CG steps on a matrix whose
+                # gathered-row part carries relative perturbations of 2^-22 (two fp16 planes per operand), a few draws
+                prt = np.random.default_rng(int(r) + 17)
+                S = A - G64
+                for _ in range(6):
+                    d = prt.uniform(-1.0, 1.0, S.shape) * 2.0 ** -22
+                    ref = max(ref, measure(als_numpy.cg_steps_f64(G64 + S * (1.0 + (d + d.T) / 2), b, X[r], 3)))
                 start = measure(X[r].astype(np.float64))
                 worst = max(worst, measure(out[r].astype(np.float64)) / max(ref, 1e-10 * start, 1e-300))
+                if VERBOSE:
+                    print(f"  row {r}: {ln[r]} entries, values {m.data[m.indptr[r]:m.indptr[r + 1]].tolist()}; squared A-norm "
+                          f"error: start {start:.3e}, device {measure(out[r].astype(np.float64)):.3e}, oracle "
+                          f"{measure(Xo[r].astype(np.float64)):.3e}, float64 CG-3 {measure(X64[r]):.3e}, reference {ref:.3e}; "
+                          f"|x| {np.linalg.norm(X64[r]):.3e}, eig(A) {np.linalg.eigvalsh(A)[[0, -3, -2, -1]].tolist()}")
             DEGENERATE.append((desc, err, float(rd.max()), float(ro.max()), worst))
             if worst > DEGENERATE_FACTOR:
                 print(f"FAIL {desc}: rel {err:.3e}; a low-rank row ends {worst:.1f}x further from its solution "
@@ -505,9 +538,14 @@ def main():
             last = time.time()
             print(f"... {n} cases, {fails} failed, last: {desc}", flush=True)
     worst = max(SENSITIVE, key=lambda t: t[1], default=None)
-    print(f"rounding-sensitive sweep cases (beyond 2e-5 of the oracle, within their measured sensitivity): {len(SENSITIVE)}"
+    print(f"rounding-sensitive sweep cases (rows with fewer than f stored entries beyond 2e-5 of the oracle, within their "
+          f"measured sensitivity): {len(SENSITIVE)}"
           + (f"; worst: {worst[0]} rel {worst[1]:.2e} (largest row distance to float64: device {worst[2]:.2e}, oracle {worst[3]:.2e})"
              if worst else ""), flush=True)
+    wf = max(FULL_RANK_BEYOND, key=lambda t: t[2], default=None)
+    print(f"sweep cases in which a row with at least f stored entries (a full-rank system) missed 2e-5 of the oracle: "
+          f"{len(FULL_RANK_BEYOND)}" + (f"; largest device / oracle distance to float64: {wf[2]:.2f} (bound 1.5) in {wf[0]}"
+                                       if wf else ""), flush=True)
     wd = max((t[4] for t in DEGENERATE), default=0.0)
     print(f"outliers in degenerate systems (fewer distinct gathered rows than f / 3): {len(DEGENERATE)}; largest ratio "
           f"of the device's squared A-norm error to the oracle's / fp32 numpy's: {wd:.2f} (bound {DEGENERATE_FACTOR:g})",
