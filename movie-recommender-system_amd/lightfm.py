@@ -351,9 +351,11 @@ class LightFM(LightFMScorer):
         st = self.__dict__.get("_dev_par")
         if st is None or st["device"] != dev:
             self._sync_params_to_host()
-            st = {"device": dev, "stale": set(),
-                  "t": {n: torch.from_numpy(np.ascontiguousarray(self.__dict__["_h_" + n], dtype=np.float32)).to(dev)
-                        for n in self._PARAMS}}
+            def up(a):
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                return torch.from_numpy(a if a.flags.writeable else a.copy()).to(dev)   # (snapshots are read-only)
+
+            st = {"device": dev, "stale": set(), "t": {n: up(self.__dict__["_h_" + n]) for n in self._PARAMS}}
             self.__dict__["_dev_par"] = st
         return st
 
@@ -402,13 +404,17 @@ class LightFM(LightFMScorer):
 
     @staticmethod
     def _fingerprint(m):
-        """Identity of an input matrix between calls: the object itself plus a cheap digest of its contents (a
-        caller may refill the same object)."""
+        """Identity of an input matrix between calls: the object itself plus a digest of ALL of its arrays (a
+        caller may refill the same object in place, with the same number of entries)."""
         if m is None:
             return None
-        d = getattr(m, "data", None)
-        return (id(m), type(m).__name__, m.shape, int(m.nnz), None if d is None else float(np.sum(d, dtype=np.float64)),
-                int(np.sum(getattr(m, "indices", getattr(m, "col", np.zeros(0)))[:4096], dtype=np.int64)))
+        import xxhash
+        h = xxhash.xxh64()
+        for name in ("data", "indices", "indptr", "row", "col"):
+            a = getattr(m, name, None)
+            if a is not None:
+                h.update(np.ascontiguousarray(a).view(np.uint8))
+        return (id(m), type(m).__name__, m.shape, int(m.nnz), h.intdigest())
 
     def _device_inputs(self, dev, interactions, user_features, item_features, sample_weight):
         """Interactions, feature matrices and sample weights as device arrays; kept from call to call while the
@@ -455,9 +461,18 @@ class LightFM(LightFMScorer):
         nc = self.no_components
         with self._lock, torch.cuda.device(dev):
             d = self._device_inputs(dev, interactions, user_features, item_features, sample_weight)
-            if self.item_embedding_gradients is None:
+            # (looked up without the property getters: those download a table the device holds the newer copy of)
+            dp = self.__dict__.get("_dev_par")
+
+            def rows_of(name):
+                if dp is not None:
+                    return int(dp["t"][name].shape[0])
+                h = self.__dict__.get("_h_" + name)
+                return None if h is None else int(h.shape[0])
+
+            if rows_of("item_embedding_gradients") is None:
                 self._initialize(d["n_uf"], d["n_if"])
-            if d["n_uf"] != self.user_embeddings.shape[0] or d["n_if"] != self.item_embeddings.shape[0]:
+            if d["n_uf"] != rows_of("user_embeddings") or d["n_if"] != rows_of("item_embeddings"):
                 raise ValueError("Incorrect number of features in user_features / item_features")
             st = self._device_params(dev)
             par = st["t"]
@@ -492,10 +507,15 @@ class LightFM(LightFMScorer):
 
 
 def _param_property(name: str) -> property:
+    """A parameter table as a numpy array.  While the device holds the newer copy (after ``fit_partial``) the getter
+    downloads it once and hands out that SNAPSHOT, marked read-only: writing into it would not reach the model --
+    assign a whole array to the attribute instead (the setter makes the host copies lead again)."""
     def getter(self):
         st = self.__dict__.get("_dev_par")
         if st is not None and name in st["stale"]:
-            self.__dict__["_h_" + name] = st["t"][name].cpu().numpy()
+            snap = st["t"][name].cpu().numpy()
+            snap.setflags(write=False)
+            self.__dict__["_h_" + name] = snap
             st["stale"].discard(name)
         return self.__dict__.get("_h_" + name)
 
