@@ -187,13 +187,6 @@ __device__ __forceinline__ const float* gather_ptr(const float* Y, int sel, int 
 template <int NT, bool FIRST, int GVN>
 __device__ __forceinline__ void step_math(const float (&yv)[GV][NT], const float (&v)[NT], float (&acc)[NT], int g0,
                                           int n, float cur_dat, int coefbase, int h, int c) {
-#ifdef MIREC_PROBE_LOADS_ONLY  // timing probe only (wrong results): the gathers and cache traffic without the arithmetic
-#pragma unroll
-    for (int j = 0; j < GVN; ++j)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] += yv[j][t];
-    return;
-#endif
     float part[GVN];
 #pragma unroll
     for (int j = 0; j < GVN; ++j) {
@@ -298,11 +291,6 @@ __device__ __forceinline__ void sparse_pass(const float (&v)[NT], float (&acc)[N
     constexpr int F = 32 * NT;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
-#ifdef MIREC_PROBE_NO_SPARSE  // timing probe only (wrong results): what the kernel costs without the gathered rows
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = v[t];
-    return;
-#endif
     const int e_idx = lane & 15;
     const int e_dat = 2 * (c >> 2) + h;   // full step: lanes 4j .. 4j+3 of a half end with entry 2j + h
     const int e_dat4 = 2 * (c >> 3) + h;  // half step: lanes 8j .. 8j+7
@@ -378,11 +366,6 @@ template <int NT>
 __device__ __forceinline__ void symv_short(const float* Gs, float* vec, const float (&v)[NT], float (&out)[NT], int h,
                                            int c) {
     constexpr int F = 32 * NT;
-#ifdef MIREC_PROBE_NO_SYMV  // timing probe only (wrong results): what the kernel costs without the G v products
-#pragma unroll
-    for (int t = 0; t < NT; ++t) out[t] = v[t];
-    return;
-#endif
     __builtin_amdgcn_wave_barrier();
     if (h == 0) store_n<NT>(vec + c * NT, v);
     __builtin_amdgcn_wave_barrier();
@@ -626,9 +609,6 @@ template <int NT>
 __device__ __forceinline__ float symv_publish(float* smem, const float (&v)[NT], float bound, int k, int seq, int lane,
                                               int h, int c) {
     using M = MfmaShort<NT>;
-#ifdef MIREC_PROBE_NO_SYMV
-    return 1.f;
-#endif
     char* vpl = reinterpret_cast<char*>(smem + M::VPL);
     constexpr int PLANEB = M::PLANE_FLOATS * 4;
     const sm_f32x2 sc = sm_scale_for(bound);
@@ -661,16 +641,9 @@ template <int NT>
 __device__ __forceinline__ void symv_collect(float* smem, const float (&v)[NT], float (&out)[NT], float unscale, int k,
                                              int seq, int c) {
     using M = MfmaShort<NT>;
-#ifdef MIREC_PROBE_NO_SYMV
-#pragma unroll
-    for (int t = 0; t < NT; ++t) out[t] = v[t];
-    return;
-#endif
     const int* done = reinterpret_cast<const int*>(smem + M::FLAGS) + 16;
     const int want = seq * M::NSRV;
-#ifndef MIREC_PROBE_NO_WAIT  // timing probe only (wrong results): the solver does not wait for its product
     while (lds_load_acquire(done + k) != want) __builtin_amdgcn_s_sleep(1);
-#endif
     const float* p0 = smem + M::PART + k * M::PART_ROW + c * NT;
     float a0[NT], a1[NT];
     load_n<NT>(a0, p0);
@@ -736,7 +709,6 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
             continue;
         }
         polls = 0;
-#ifndef MIREC_PROBE_NO_MFMA  // timing probe only (wrong results): the servers count products done without evaluating them
         // the units of a server share their k part: its vector operands are read once per sweep
         static_assert(M::UPS <= M::TILES && M::TILES % M::UPS == 0, "the units of a server lie in one k part");
         const int kp = (srv * M::UPS) / M::TILES;
@@ -763,25 +735,12 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
             // (the others were read while their solver may have been writing them)
             if (pend) *reinterpret_cast<f32x4*>(part + (kp * M::COLS + n) * M::PART_ROW + 16 * t + 4 * q) = acc;
         }
-#endif
         seen = pubv;
         // the release orders this wavefront's stores before the counts
         if (pend && q == 0) __hip_atomic_fetch_add(done + n, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-// Optional phase timing (-DMIREC_DEBUG_TIMING): cycle counts of the phases of a row, of the first solver of every
-// workgroup, summed into a counter array that mirec_short_debug_read returns (tools/probes/short_phase_timing.py).
-// 1 M x 27 k user half-sweep, per row of 35 k cycles: header 1.0 k, four publishes 2.0 k, first pass 7.5 k, four
-// waits for the servers 8.9 k, three later passes 12.8 k, vector updates 1.3 k.
-#ifdef MIREC_DEBUG_TIMING
-static __device__ unsigned long long mirec_short_dbg[16];
-#define SHT_T() __builtin_readcyclecounter()
-#define SHT_ADD(i, v) sdbg[i] += (v)
-#else
-#define SHT_T() 0ull
-#define SHT_ADD(i, v)
-#endif
 
 template <int NT, bool BIG>
 __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
@@ -813,13 +772,9 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
     float* cache = smem + M::CACHE + w * (CAP * F);
     int seq = 0;  // products this solver has published
 
-#ifdef MIREC_DEBUG_TIMING
-    unsigned long long sdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     // the solvers of a workgroup take consecutive rows of the plan's list (rows of about equal length)
     const int64_t stride = (int64_t)gridDim.x * M::NS;
     for (int64_t r = (int64_t)blockIdx.x * M::NS + w; r < n_short; r += stride) {
-        const unsigned long long s0 = SHT_T();
         const int64_t row = row_begin + order[r];
         const int64_t rs = indptr[row];
         const int n = (int)(indptr[row + 1] - rs);
@@ -840,18 +795,9 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
         float part = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) part = fmaf(x[t], x[t], part);
-        const unsigned long long s1 = SHT_T();
         float unscale = symv_publish<NT>(smem, x, sqrtf(half_sum(part)), w, ++seq, lane, h, c) * gsc[1];
-        const unsigned long long s2 = SHT_T();
         sparse_pass<NT, CAP, true, BIG, RS>(x, acc, ind, dat, Y, cache, n, lane, h, c, R);
-        const unsigned long long s3 = SHT_T();
         symv_collect<NT>(smem, x, Ap, unscale, w, seq, c);
-        const unsigned long long s4 = SHT_T();
-        SHT_ADD(0, s1 - s0);  // row header, x, norm
-        SHT_ADD(1, s2 - s1);  // publish
-        SHT_ADD(2, s3 - s2);  // first pass (gathers)
-        SHT_ADD(3, s4 - s3);  // collect (wait for the servers)
-        SHT_ADD(7, 1);
         part = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -863,16 +809,9 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
         if (rsold < 1e-20f) continue;
         float pbound = sqrtf(rsold) * 1.0001f;  // |p| for p = r; afterwards |r + beta p| <= |r| + beta |p|
         for (int it = 0; it < cg_steps; ++it) {
-            const unsigned long long c0 = SHT_T();
             unscale = symv_publish<NT>(smem, p, pbound, w, ++seq, lane, h, c) * gsc[1];
-            const unsigned long long c1 = SHT_T();
             sparse_pass<NT, CAP, false, BIG, RS>(p, acc, ind, dat, Y, cache, n, lane, h, c, R);
-            const unsigned long long c2 = SHT_T();
             symv_collect<NT>(smem, p, Ap, unscale, w, seq, c);
-            const unsigned long long c3 = SHT_T();
-            SHT_ADD(1, c1 - c0);
-            SHT_ADD(4, c2 - c1);  // later passes
-            SHT_ADD(3, c3 - c2);
             part = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -894,15 +833,9 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
             for (int t = 0; t < NT; ++t) p[t] = fmaf(beta, p[t], rr[t]);
             pbound = (sqrtf(rsnew) + fabsf(beta) * pbound) * 1.0001f;
             rsold = rsnew;
-            SHT_ADD(5, SHT_T() - c3);  // vector updates of a CG step
         }
         if (h == 0) store_n<NT>(xg, x);
-        SHT_ADD(6, SHT_T() - s0);  // whole row
     }
-#ifdef MIREC_DEBUG_TIMING
-    if (w == 0 && lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&mirec_short_dbg[i], sdbg[i]);
-#endif
     // every product this solver published has been collected: the servers may stop once all solvers are here
     if (lane == 0) __hip_atomic_fetch_add(flags + 32, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -970,13 +903,11 @@ static int launch_short_nt(int64_t y_rows, const int64_t* indptr, const int32_t*
                            hipStream_t stream) {
     // byte offsets into the gathered table are kept in 32 bits while the whole table is addressable that way
     const bool big = y_rows <= 0 || (uint64_t)y_rows * (32u * NT * 4u) > (1ull << 32);
-#ifndef MIREC_SHORT_VALU_ONLY
     if constexpr (NT == 2 || NT == 4) {
         if (order != nullptr)
             return big ? launch_short_mfma<NT, true>(indptr, indices, data, row_begin, X, Y, G, cg_steps, order, n_short, stream)
                        : launch_short_mfma<NT, false>(indptr, indices, data, row_begin, X, Y, G, cg_steps, order, n_short, stream);
     }
-#endif
     return big ? launch_short<NT, true>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream)
                : launch_short<NT, false>(indptr, indices, data, row_begin, nrows, X, Y, G, short_max, cg_steps, stream);
 }
@@ -999,13 +930,8 @@ int launch_als_short(int nt, int64_t y_rows, const int64_t* indptr, const int32_
 int als_short_cache_rows(int nt) {
     switch (nt) {
         case 1: return ShortLds<1>::CAP;
-#ifdef MIREC_SHORT_VALU_ONLY
-        case 2: return ShortLds<2>::CAP;
-        case 4: return ShortLds<4>::CAP;
-#else
         case 2: return MfmaShort<2>::CAP + MfmaShort<2>::RS * STEP;
         case 4: return MfmaShort<4>::CAP + MfmaShort<4>::RS * STEP;
-#endif
         case 3: return ShortLds<3>::CAP;
         case 5: return ShortLds<5>::CAP;
         case 6: return ShortLds<6>::CAP;
@@ -1015,13 +941,3 @@ int als_short_cache_rows(int nt) {
 
 }  // namespace mirec
 
-#ifdef MIREC_DEBUG_TIMING
-extern "C" int mirec_short_debug_read(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mirec::mirec_short_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -3;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(mirec::mirec_short_dbg), z, sizeof(z)) != hipSuccess) return -3;
-    }
-    return 0;
-}
-#endif

@@ -467,16 +467,6 @@ __device__ void chol_solve_block(float* A, const float* b, float* pan, float* xg
     }
 }
 
-// Optional in-kernel phase timing (-DMIREC_DEBUG_TIMING): per-wave cycle counts summed into mirec_dbg and
-// read back with mirec_debug_read; tools/probes/gram_phase_timing.py prints them.
-#ifdef MIREC_DEBUG_TIMING
-__device__ unsigned long long mirec_dbg[16];
-#define DBG_T() __builtin_readcyclecounter()
-#define DBG_ADD(i, v) atomicAdd(&mirec_dbg[i], (unsigned long long)(v))
-#else
-#define DBG_T() 0ull
-#define DBG_ADD(i, v) do { } while (0)
-#endif
 
 // ------------------------------------------------------------- kernels -----
 // Geometry of the explicit-Gram kernel at width F = 32*NT:
@@ -554,10 +544,6 @@ __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
 __device__ __forceinline__ void split2x2(f32x2 a, f32x2 b, uint32_t (&hi)[2], uint32_t (&mid)[2]) {
     hi[0] = cvt_pk_f16(a[0], b[0]);
     hi[1] = cvt_pk_f16(a[1], b[1]);
-#ifdef MIREC_PROBE_NO_SPLIT  // timing probe only (wrong results): what the producers cost without the plane split
-    mid[0] = hi[0]; mid[1] = hi[1];
-    return;
-#endif
     const f16x2 h0 = __builtin_bit_cast(f16x2, hi[0]), h1 = __builtin_bit_cast(f16x2, hi[1]);
     a -= f32x2{(float)h0[0], (float)h1[0]};
     b -= f32x2{(float)h0[1], (float)h1[1]};
@@ -719,7 +705,6 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
     // columns 2*c2 + t: rows 2*c2 + (t ^ ((c2 >> 1) & 1)) of a plane, chunk eg at position eg ^ swz
     const int wswap = (c2 >> 1) & 1;
     const int wbase = c2 * 128 + ((eg ^ C::col_swz(2 * c2)) << 4);
-    unsigned long long dbg_a = 0, dbg_s[5] = {0, 0, 0, 0, 0};
     auto store_tile = [&](const f32x2 (&yv)[8], const float (&dd)[8], int buf) __attribute__((always_inline)) {
         char* tile = tiles + buf * C::TILE_BYTES;
         uint32_t* sm = smask + buf * 16;
@@ -736,7 +721,6 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
         }
         // b is final for this tile before the next gathers overwrite yv
         asm volatile("" : "+v"(bacc0), "+v"(bacc1));
-        dbg_a = DBG_T();
         u32x4 hi[2], mid[2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -771,26 +755,12 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
     auto phase = [&](auto set, auto steady, int tile) __attribute__((always_inline)) {
         constexpr int S = decltype(set)::value;
         constexpr bool STEADY = decltype(steady)::value;
-        const unsigned long long t0 = DBG_T();
-        unsigned long long t1 = t0, t2 = t0;
         if (STEADY || tile + 1 < ntiles) {
             store_tile(yv2[S ^ 1], dd2[S ^ 1], S ^ 1);
-            t1 = DBG_T();
             if (STEADY || tile + 4 < ntiles) load_idx(idx2[S], STEADY || is_full(tile + 4));
             if (STEADY || tile + 3 < ntiles) load_rows(idx2[S ^ 1], yv2[S ^ 1], dd2[S ^ 1], STEADY || is_full(tile + 3));
-            t2 = DBG_T();
         }
         __syncthreads();  // tile + 1 is in LDS; the consumers are done with tile
-#ifdef MIREC_DEBUG_TIMING
-        if (STEADY) {
-            const unsigned long long t3 = DBG_T();
-            dbg_s[0] += dbg_a - t0;  // wait for rows + weights + b
-            dbg_s[1] += t1 - dbg_a;  // split + LDS stores
-            dbg_s[2] += t2 - t1;     // issue of the next loads
-            dbg_s[3] += t3 - t2;     // barrier
-            dbg_s[4] += 1;
-        }
-#endif
     };
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
@@ -815,10 +785,6 @@ __device__ __forceinline__ void gram_producer(const int32_t* __restrict__ indice
     }
     bred[eg * F + 2 * c2] = bacc0;
     bred[eg * F + 2 * c2 + 1] = bacc1;
-#ifdef MIREC_DEBUG_TIMING
-    if (ptid == 0)
-        for (int i = 0; i < 5; ++i) DBG_ADD(i, dbg_s[i]);
-#endif
 }
 
 // Consumer wave W: accumulates its tiles over the chunk, then stores them (executes the same barriers as the
@@ -840,24 +806,10 @@ __device__ __forceinline__ void gram_consumer(const float* __restrict__ G, int n
     for (int j = 0; j < WA::N1; ++j) A.a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();
-    unsigned long long dbg_w = 0, dbg_b = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
-        const unsigned long long t0 = DBG_T();
-#ifndef MIREC_PROBE_NO_GRAM  // timing probe only (wrong results): the consumers skip the matrix work
         gram_tile<NT, W>(tiles + (tile & 1) * C::TILE_BYTES, smask + (tile & 1) * 16, A, lane);
-#endif
-        const unsigned long long t1 = DBG_T();
         __syncthreads();
-        dbg_w += t1 - t0;
-        dbg_b += DBG_T() - t1;
     }
-#ifdef MIREC_DEBUG_TIMING
-    if (W == 0 && lane == 0) {
-        DBG_ADD(8, dbg_w);
-        DBG_ADD(9, dbg_b);
-        DBG_ADD(10, ntiles);
-    }
-#endif
     // every consumer is past its last tile, so the tile buffers that alias `big` are free
 
     const int q = lane >> 4, i = lane & 15;
@@ -921,7 +873,6 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const unsigned long long dbg_k0 = DBG_T();
 
     const int chunk = blockIdx.x;
     const int r = chunk_row[chunk];
@@ -974,7 +925,6 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
     }
     if (w >= NT) gram_producer<NT, BIG>(indices, data, Y, ks, ke, smem, tid - 64 * NT, scale2);
     __syncthreads();  // A (or the partial slot) and the b partials of the four entry groups are written
-    const unsigned long long dbg_k1 = DBG_T();
     if (tid < F) {
         const float b = (bred[tid] + bred[F + tid]) + (bred[2 * F + tid] + bred[3 * F + tid]);
         if (single) bvec[tid] = b;
@@ -985,13 +935,6 @@ __global__ __launch_bounds__(128 * NT, (NT <= 4 ? 4 : 1)) void als_gram_cg_kerne
         if constexpr (EXACT) chol_solve_block<F, NTHR>(big, bvec, smem + C::CHOL_PANEL, xrow, tid);
         else cg_solve_block<F, 2 * NT>(big, bvec, vec, smem + C::CGP, xrow, cg_steps, tid);
     }
-#ifdef MIREC_DEBUG_TIMING
-    if (tid == 0) {
-        DBG_ADD(12, dbg_k1 - dbg_k0);    // whole chunk up to the stored A / partial
-        DBG_ADD(13, DBG_T() - dbg_k1);   // b sum + CG
-        DBG_ADD(14, 1);
-    }
-#endif
 }
 
 // Split rows: sum the chunk partials in chunk order, add G, mirror the upper triangle, solve.
@@ -1139,16 +1082,6 @@ static int launch_sweep(const int64_t* indptr, const int32_t* indices, const flo
 
 using namespace mirec;
 
-#ifdef MIREC_DEBUG_TIMING
-extern "C" int mirec_debug_read(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mirec_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -3;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(mirec_dbg), z, sizeof(z)) != hipSuccess) return -3;
-    }
-    return 0;
-}
-#endif
 
 extern "C" size_t mirec_als_plan_bytes(int64_t nrows, int64_t nnz, int32_t chunk_nnz) {
     if (nrows < 0 || nnz < 0) return 0;

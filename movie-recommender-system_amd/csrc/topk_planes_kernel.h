@@ -51,25 +51,14 @@
 // for the previous design (four matrix wavefronts handing score tiles through LDS to eight selector wavefronts,
 // item-per-lane).  Counters: 385 instructions per wavefront and tile (180 vector, 24 matrix, 137 scalar, 39 LDS),
 // the matrix pipe 28 % busy -- the sweep is bound by instruction issue of the selection, not by the products.
-// Probe builds (-DMIREC_PROBE_TK_NOSCAN, _NOWALK, _NOMFMA, _NOSYNC; wrong results, timing only) leave out
-// one part each: without the matrix instructions 13.7 ms, without selection and walk 17.4 ms.
+// Builds that leave out one part each (wrong results, timing only; tools/probes/patches): without the matrix
+// instructions 13.7 ms, without selection and walk 17.4 ms.
 #pragma once
 #include "topk_kernel.h"
 #include "topk_workspace.h"
 
 namespace mirec {
 
-// Optional phase timing (-DMIREC_DEBUG_TIMING): cycle counts of the sections of the sweep, of the first wavefront
-// of every workgroup, summed into a per-translation-unit counter array; the F = 128 unit exports
-// mirec_topk_debug_read (tools/probes/topk_phase_timing.py).
-#ifdef MIREC_DEBUG_TIMING
-static __device__ unsigned long long mirec_topk_dbg[16];
-#define TKS_T() __builtin_readcyclecounter()
-#define TKS_ADD(i, v) dbg[i] += (v)
-#else
-#define TKS_T() 0ull
-#define TKS_ADD(i, v)
-#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 tk_bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 tk_bf16x2;
@@ -527,10 +516,6 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     auto kstep = [&](int s) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         const tk_u32x4(&a)[TOPK_NPLANES] = ya[s % 3];
-#ifdef MIREC_PROBE_TK_NOMFMA
-        acc0[s] += __uint_as_float(a[0][0] ^ qh[s][1]);
-        acc1[s] += __uint_as_float(a[1][2] ^ qm[s][3]);
-#else
         // mid * mid is below 2^-18 of |q_k y_k| and left to the margin; the first use of an accumulator starts
         // it from zero (an operand of the instruction, not a register fill)
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -543,7 +528,6 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             acc1 = tk_mma(a[1], qh[s], s == 0 ? zero : acc1);
             acc0 = tk_mma(a[0], qm[s], acc0);
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < KS) fetch(s + 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -561,12 +545,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     if (lane == 0) tk_store_release(read_done + w, 1);
 
     float sc[16];
-#ifdef MIREC_DEBUG_TIMING
-    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     for (int t = 0; t < ntile; ++t) {
         const int i0 = t * BI;
-        const unsigned long long c0 = TKS_T();
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = acc0[i] + acc1[i];
         if (t == ntile - 1) {  // rows past the last item
@@ -577,34 +557,21 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         // the next tile (after the last one: the last one again, for nothing); every wavefront has stored its
         // share of its image
         const int tn = t + 1 < ntile ? t + 1 : t;
-        const unsigned long long c1 = TKS_T();
-#ifndef MIREC_PROBE_TK_NOSYNC
         if (tn >= 3) tk_wait_all<NW>(staged, tn + 1, lane);
-#endif
-        const unsigned long long c2 = TKS_T();
         yb = ybuf + (tn % PD) * L::TILEB + c * L::ROWB + 16 * h;
         fetch(0);
         if (KS > 1) fetch(1);
 
         // liked items of the tile (walker lanes)
-#ifdef MIREC_PROBE_TK_NOWALK
-        const unsigned mw = 0u;
-#else
         mask_refill_commit();
         const unsigned mw = walk_tile(i0);
-#endif
 
-        const unsigned long long c3 = TKS_T();
         float best4[4];  // of the four groups of four scores (items 8 g + 4 h .. + 3 of the tile)
 #pragma unroll
         for (int g = 0; g < 4; ++g) best4[g] = fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3]));
         const float best = fmaxf(fmaxf(best4[0], best4[1]), fmaxf(best4[2], best4[3]));
         unsigned fail = 0u;
-#ifdef MIREC_PROBE_TK_NOSCAN
-        if (best == 12345.f && __ballot(best > thr) != 0ull) {
-#else
         if (__ballot(best > thr) != 0ull) {
-#endif
             // liked bits of this lane's 16 items: bit tk_rowpos(i)
             unsigned liked = 0u;
             if (mask_indptr != nullptr) liked = (unsigned)__builtin_amdgcn_ds_bpermute(c << 2, (int)mw) >> (4 * h);
@@ -627,7 +594,6 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             for (int s = 0; s < KS; ++s) kstep(s);
         }
         if (lane == 0) tk_store_release(read_done + w, tn + 1);  // this wavefront is done with the image of tile tn
-        const unsigned long long c4 = TKS_T();
 
         // Buffers that were full: compact (every query of the wavefront, which raises all thresholds) and offer
         // the candidates that were turned away again.  A second compaction covers a tile whose candidates
@@ -670,32 +636,15 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             }
         }
 
-        const unsigned long long c5 = TKS_T();
-        unsigned long long c6 = c5;
         if (t + 3 < ntile) {
             // the image that tile t + 3 replaces was that of tile t + 3 - PD: everybody must be done reading it
-#ifndef MIREC_PROBE_TK_NOSYNC
             if (t + 4 - PD >= 1) tk_wait_all<NW>(read_done, t + 4 - PD, lane);
-#endif
-            c6 = TKS_T();
             store_y(ybuf + ((t + 3) % PD) * L::TILEB);
             if (lane == 0) tk_store_release(staged + w, t + 4);
             load_y(t + 4 < ntile ? t + 4 : ntile - 1);
         }
-#ifndef MIREC_PROBE_TK_NOWALK
         mask_refill_issue();
-#endif
-        TKS_ADD(0, c1 - c0);           // scores out of the accumulators (waits for the matrix pipe)
-        TKS_ADD(1, c2 - c1);           // wait: next image staged
-        TKS_ADD(2, c3 - c2);           // liked-item walk
-        TKS_ADD(3, c4 - c3);           // selection steps + matrix instructions of the next tile
-        TKS_ADD(4, c5 - c4);           // compactions and second offers
-        TKS_ADD(5, c6 - c5);           // wait: image to be replaced is read
-        TKS_ADD(6, TKS_T() - c6);      // staging
     }
-#ifdef MIREC_DEBUG_TIMING
-    const unsigned long long cf = TKS_T();
-#endif
 
     // ---- margin set -> exact scores -> the k best, for the 32 queries of the wavefront
     bool over;
@@ -777,13 +726,6 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             out_scores[uq * k + c] = -FLT_MAX;
         }
     }
-#ifdef MIREC_DEBUG_TIMING
-    if (tid == 0) {
-        for (int i = 0; i < 7; ++i) atomicAdd(&mirec_topk_dbg[i], dbg[i]);
-        atomicAdd(&mirec_topk_dbg[7], TKS_T() - cf);  // final stage
-        atomicAdd(&mirec_topk_dbg[8], (unsigned long long)ntile);
-    }
-#endif
 }
 
 template <int F, int NW, int CAP, int PD>
