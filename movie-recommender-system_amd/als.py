@@ -422,7 +422,9 @@ class AlternatingLeastSquares:
                 att = self._attached
                 if att is not None and (user_items is None or user_items is att[0]):
                     d = att[1]                     # the attached matrix: its rows as a view, nothing uploaded
-                    dmask = E.DeviceCSR(d.indptr[u0:u1 + 1], d.indices, d.data, (u1 - u0, d.shape[1]))
+                    if u1 - u0 > (1 << 17):
+                        d.build_order()            # once per attached matrix: the sweep order of the all-users pass
+                    dmask = d.rows(u0, u1)
                 else:
                     if user_items is None:
                         raise ValueError("user_items is needed to filter liked items")
@@ -430,6 +432,8 @@ class AlternatingLeastSquares:
                     if not m.has_sorted_indices:
                         m = m.sorted_indices()
                     dmask = E.DeviceCSR.from_scipy(m, dev)
+                    if u1 - u0 > (1 << 17):
+                        dmask.build_order()
             n = Q.shape[0]
             if n <= (1 << 17):
                 ids, scores = E.topk(Q, Yd, int(N), dmask)
@@ -439,8 +443,7 @@ class AlternatingLeastSquares:
             dl = E.ChunkedDownload(n, int(N), dev)
             for a, b in dl.ranges():
                 # (the kernels index the filter's row pointers by query and read absolute offsets: a view will do)
-                m = None if dmask is None else E.DeviceCSR(dmask.indptr[a:b + 1], dmask.indices, dmask.data,
-                                                           (b - a, dmask.shape[1]))
+                m = None if dmask is None else dmask.rows(a, b)
                 ids, scores = E.topk(Q[a:b], Yd, int(N), m, path="sweep")
                 dl.submit(_hide_filtered(ids, scores, m), scores, a)
             return dl.finish()

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(HERE, "libmirec.so")
-SOURCES = ["core.hip", "gram.hip", "als_sweep.hip", "als_short.hip", "plan_sort.hip", "topk.hip", "topk_small.hip", "topk_inst_0.hip", "topk_inst_1.hip",
+SOURCES = ["core.hip", "gram.hip", "als_sweep.hip", "als_short.hip", "plan_sort.hip", "topk.hip", "topk_small.hip", "topk_order.hip", "topk_inst_0.hip", "topk_inst_1.hip",
            "topk_inst_2.hip", "topk_inst_3.hip", "topk_inst_4.hip", "topk_inst_5.hip", "lightfm.hip", "lightfm_train.hip", "transpose.hip", "metrics.hip", "build_matrix.hip"]
 HEADERS = sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join(ROOT, "include", "mirec.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",

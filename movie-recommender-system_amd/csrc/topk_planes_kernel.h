@@ -109,6 +109,7 @@ constexpr float topk_eps_coef() {
 // max ||y|| (atomic max on the bits of the non-negative norm; a NaN norm has the largest bits).
 template <int F>
 __global__ __launch_bounds__(32 * (F / 8)) void topk_split_items_kernel(const float* __restrict__ Y, int64_t ni,
+                                                                       const int32_t* __restrict__ order,
                                                                        uint32_t* __restrict__ planes,
                                                                        uint32_t* __restrict__ ymax_bits) {
     constexpr int F8 = F / 8;
@@ -117,7 +118,12 @@ __global__ __launch_bounds__(32 * (F / 8)) void topk_split_items_kernel(const fl
     const int tid = threadIdx.x;
     const int j = tid / F8;
     const int kc = tid % F8;
-    const int64_t item = (int64_t)blockIdx.x * 32 + j;
+    // row j of the tile is the item at that position of the sweep (its own index without an order)
+    int64_t item = (int64_t)blockIdx.x * 32 + j;
+    if (order != nullptr && item < ni) {
+        const int64_t o = order[item];
+        item = o < 0 ? 0 : (o < ni ? o : ni - 1);
+    }
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     if (item < ni) {
         a = *reinterpret_cast<const f32x4*>(Y + item * F + 8 * kc);
@@ -280,9 +286,9 @@ template <int F, int NW, int CAP, int PD>
 __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const float* __restrict__ Q, int64_t nq, const float* __restrict__ Y, int64_t ni,
     const uint32_t* __restrict__ planes, const uint32_t* __restrict__ ymax_bits,
-    const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices, int k,
-    int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int32_t* __restrict__ qlist,
-    int32_t* __restrict__ qcount) {
+    const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices,
+    const int32_t* __restrict__ order, int k, int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
+    int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
     using L = TopkPlanesLds<F, NW, CAP, PD>;
     constexpr int KS = F / 16;  // MFMA k-steps
     constexpr int F8 = F / 8;   // 16-byte chunks per plane row
@@ -672,7 +678,12 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             const int e = 2 * j + h;
             const bool act = e < nfin;
             if (__ballot(act) == 0ull) break;
-            const int id = act ? sel_i[e * NQ + q] : 0;
+            int id = act ? sel_i[e * NQ + q] : 0;
+            if (order != nullptr) {  // the buffers hold positions of the sweep: from here on, items
+                id = order[id];
+                id = id < 0 ? 0 : (id < ni ? id : (int)ni - 1);
+                if (act) sel_i[e * NQ + q] = id;
+            }
             const float* yr = Y + (int64_t)id * F;
             float s = 0.f;
             // the row in groups of G 16-byte loads, the next group in flight during the chain of the current one
@@ -730,8 +741,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
 
 template <int F, int NW, int CAP, int PD>
 static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
-                                  const int32_t* mask_indices, int k, int32_t* out_ids, float* out_scores, void* ws,
-                                  hipStream_t stream) {
+                                  const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_positions,
+                                  int k, int32_t* out_ids, float* out_scores, void* ws, hipStream_t stream) {
     using L = TopkPlanesLds<F, NW, CAP, PD>;
     static_assert(L::BYTES <= 160 * 1024, "top-K plane kernel: LDS image too large");
     static OncePerDevice once;  // idempotent; a race only repeats the call
@@ -751,12 +762,14 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
     const int ntile = (int)((ni + TOPK_BI - 1) / TOPK_BI);
 
     MIREC_HIP(hipMemsetAsync(base, 0, 256, stream));
-    hipLaunchKernelGGL((topk_split_items_kernel<F>), dim3((unsigned)ntile), dim3(32 * (F / 8)), 0, stream, Y, ni, planes,
-                       ymax_bits);
+    hipLaunchKernelGGL((topk_split_items_kernel<F>), dim3((unsigned)ntile), dim3(32 * (F / 8)), 0, stream, Y, ni,
+                       item_order, planes, ymax_bits);
     MIREC_LAUNCH_CHECK();
     const int64_t blocks = (nq + L::NQ - 1) / L::NQ;
+    // with an order the sweep meets positions, and the filter rows it walks are those renumbered to positions
     hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream, Q, nq,
-                       Y, ni, planes, ymax_bits, mask_indptr, mask_indices, k, out_ids, out_scores, qlist, qcount);
+                       Y, ni, planes, ymax_bits, mask_indptr, item_order != nullptr ? mask_positions : mask_indices,
+                       item_order, k, out_ids, out_scores, qlist, qcount);
     MIREC_LAUNCH_CHECK();
     // the queries handed over (none, as a rule): the fp32 kernel in list mode, sized for the worst case
     return launch_topk_fused<F>(Q, nq, Y, ni, mask_indptr, mask_indices, nullptr, nullptr, k, out_ids, out_scores, qlist,
@@ -767,16 +780,17 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
 // k > 24, for the similar-items mode (per-score divisions) and for tiny item sets the fp32 kernel runs alone.
 template <int F>
 int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
-                const int32_t* mask_indices, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
-                float* out_scores, void* ws, size_t ws_bytes, hipStream_t stream) {
+                const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_positions,
+                const float* y_norm, const float* q_norm, int k, int32_t* out_ids, float* out_scores, void* ws,
+                size_t ws_bytes, hipStream_t stream) {
     if constexpr (F % 16 == 0 && F <= 128) {
         if (ws != nullptr && y_norm == nullptr && q_norm == nullptr && topk_planes_supported(F, k) && ni >= 2 * TOPK_BI) {
             MIREC_REQUIRE(ws_bytes >= topk_workspace_layout(nq, ni, F).bytes, MIREC_E_INVALID,
                           "mirec_topk: workspace of %zu bytes given, mirec_topk_workspace_bytes asks for %zu", ws_bytes,
                           topk_workspace_layout(nq, ni, F).bytes);
             MIREC_REQUIRE(((uintptr_t)ws & 255) == 0, MIREC_E_INVALID, "mirec_topk: workspace must be 256-byte aligned");
-            return launch_topk_planes_cfg<F, 8, 48, 3>(Q, nq, Y, ni, mask_indptr, mask_indices, k, out_ids, out_scores, ws,
-                                                       stream);
+            return launch_topk_planes_cfg<F, 8, 48, 3>(Q, nq, Y, ni, mask_indptr, mask_indices, item_order, mask_positions,
+                                                       k, out_ids, out_scores, ws, stream);
         }
     }
     return launch_topk_fused<F>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids, out_scores, nullptr,

@@ -1,7 +1,7 @@
 """Does the order of the item sweep matter to the top-K pass?  Trains the benchmark's factors for a few iterations,
-then times the all-users top-20 with the items in their own order and in the order of descending norm (the liked
-rows are renumbered and re-sorted to match): with the largest scores met first the thresholds rise early and fewer
-candidates are appended.  Checks that both orders name the same items.
+then times the all-users top-20 with the items in their own order, in the order mirec_topk_order_build makes
+(descending number of interactions) and in the order of descending norm: with the largest scores met first the
+thresholds rise early and few tiles hold a candidate.  Checks that all orders give the same bits.
 
 usage: topk_item_order.py [iterations]
 """
@@ -47,14 +47,25 @@ def timed(Yt, mask, tag):
 
 
 ids0, sc0 = timed(Y, Cui, "items in their own order")
-order = torch.argsort(norms, descending=True, stable=True)          # new position -> item
+
+mask = E.DeviceCSR(indptr, indices, data, (U, I))
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+mask.build_order()
+b.record()
+torch.cuda.synchronize()
+print("order build (once per matrix): %.2f ms" % a.elapsed_time(b), flush=True)
+ids1, sc1 = timed(Y, mask, "by descending interactions")
+print("same bits:", bool((ids1 == ids0).all()) and bool((sc1 == sc0).all()), flush=True)
+
+# any permutation may be handed in: by descending norm of the trained factors
+order = torch.argsort(norms, descending=True, stable=True)          # position -> item
 pos = torch.empty_like(order)
-pos[order] = torch.arange(I, device=dev)                            # item -> new position
+pos[order] = torch.arange(I, device=dev)                            # item -> position
 rows = torch.repeat_interleave(torch.arange(U, device=dev), indptr[1:] - indptr[:-1])
-key = rows * I + pos[indices.long()]
-key, _ = torch.sort(key)
-mask = E.DeviceCSR(indptr, (key % I).to(torch.int32), data, (U, I))
-ids1, sc1 = timed(Y[order].contiguous(), mask, "items by descending norm")
-back = order[ids1.long().clamp(min=0)].to(torch.int32)
-same_sets = bool((torch.sort(back, dim=1).values == torch.sort(ids0, dim=1).values).all())
-print("same items named:", same_sets, " same scores:", bool((torch.sort(sc1, dim=1).values == torch.sort(sc0, dim=1).values).all()))
+key, _ = torch.sort(rows * I + pos[indices.long()])
+mask2 = E.DeviceCSR(indptr, indices, data, (U, I))
+mask2.order = (order.to(torch.int32), (key % I).to(torch.int32))
+ids2, sc2 = timed(Y, mask2, "by descending norm")
+print("same bits:", bool((ids2 == ids0).all()) and bool((sc2 == sc0).all()), flush=True)
