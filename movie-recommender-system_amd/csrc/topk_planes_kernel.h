@@ -94,23 +94,31 @@ __device__ __forceinline__ f32x16 tk_mma(const tk_u32x4& a, const tk_u32x4& b, f
                                                    0, 0, 0);
 }
 
-// |s~ - s| <= topk_eps_coef<F>() * ||q|| * max||y||: the factors' third bf16 planes, which are dropped
-// (|x - hi - mid| <= 2^-18 |x| on either side: 2^-17 in all), the mid * mid plane product, which is not
-// formed (|mid| <= 2^-9 |x|: 2^-18), the F roundings of the fp32 chain and the
-// roundings of the matrix pipe's accumulation -- the latter with a wide safety factor on the typical
-// (random-walk) error, which is below 2^-24 of sum |q_k y_k|.
+// |s~ - s| <= topk_eps_coef<F>() * ||q|| * max||y||.  Rounding to bf16 leaves |x - hi| <= 2^-8 |x| and, of
+// that remainder, |x - hi - mid| <= 2^-17 |x|; so the factors' third planes, which are dropped, account for
+// 2^-16 (2^-17 on either side, Cauchy-Schwarz over the row), the mid * mid plane product, which is not formed, for
+// another 2^-16, and the roundings of the fp32 chain and of the matrix pipe's accumulation for (8 F + 64) 2^-24,
+// several times what F sequential and 3 F pipelined additions can lose.
 template <int F>
 constexpr float topk_eps_coef() {
-    return ((float)(8 * F + 64) * 5.9604644775390625e-8f + 7.62939453125e-6f + 3.814697265625e-6f) * 1.01f;
+    return ((float)(8 * F + 64) * 5.9604644775390625e-8f + 1.52587890625e-5f + 1.52587890625e-5f) * 1.01f;
+}
+// |s~ - hi.hi| <= topk_coarse_coef<F>() * ||q|| * ||y||: the two products with a mid plane,
+// |hi_q . mid_y| + |mid_q . hi_y| <= 2 * 2^-8 (1 + 2^-8) ||q|| ||y||, and the roundings of the accumulation.
+template <int F>
+constexpr float topk_coarse_coef() {
+    return (0.0078125f * 1.00390625f + (float)(8 * F + 64) * 5.9604644775390625e-8f) * 1.01f;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Item factors -> bf16 planes (one workgroup per item tile, one thread per 8 consecutive factors) and
-// max ||y|| (atomic max on the bits of the non-negative norm; a NaN norm has the largest bits).
+// Item factors -> bf16 planes (one workgroup per item tile, one thread per 8 consecutive factors), the largest
+// row norm of every tile and max ||y|| (atomic max on the bits of the non-negative norm; a NaN norm has the
+// largest bits).
 template <int F>
 __global__ __launch_bounds__(32 * (F / 8)) void topk_split_items_kernel(const float* __restrict__ Y, int64_t ni,
                                                                        const int32_t* __restrict__ order,
                                                                        uint32_t* __restrict__ planes,
+                                                                       float* __restrict__ tile_norm,
                                                                        uint32_t* __restrict__ ymax_bits) {
     constexpr int F8 = F / 8;
     __shared__ float part[32 * F8];
@@ -151,6 +159,9 @@ __global__ __launch_bounds__(32 * (F / 8)) void topk_split_items_kernel(const fl
             m = v > m ? v : m;
         }
         atomicMax(ymax_bits, m);
+        // the tile's largest row norm, rounded up past what the sum of squares above may have lost; a norm
+        // that is not a number (the largest bits) stays one
+        tile_norm[blockIdx.x] = __uint_as_float(m) * 1.0001f;
     }
 }
 
@@ -195,23 +206,24 @@ __device__ __forceinline__ void tk_wait_all(const int* p, int need, int lane) {
 template <int F, int NW, int CAP, int PD>
 struct TopkPlanesLds {
     static constexpr int NQ = 32 * NW;  // queries of a workgroup
-    // One plane of an item tile: 32 rows of F bf16, padded by 16 bytes: the row stride in dwords is an odd
-    // multiple of four, which puts the 16 rows of every ds_read_b128 group on disjoint banks.
+    // The hi plane of an item tile: 32 rows of F bf16, padded by 16 bytes: the row stride in dwords is an odd
+    // multiple of four, which puts the 16 rows of every ds_read_b128 group on disjoint banks.  An image is
+    // filled by loads that write LDS directly, 1 KiB (64 lanes x 16 bytes, consecutive) per instruction.
     static constexpr int ROWB = 2 * F + 16;
-    static constexpr int PLANEB = TOPK_BI * ROWB;
-    static constexpr int TILEB = TOPK_NPLANES * PLANEB;
+    static constexpr int IMGB = TOPK_BI * ROWB;
+    static constexpr int NPIECE = (IMGB + 1023) / 1024;
+    static constexpr int NPW = (NPIECE + NW - 1) / NW;  // pieces a wavefront issues per tile, at most
     static constexpr int RING = 8;  // liked-item look-ahead per query (a power of two, at least 8)
     // in floats: the item images; candidate scores and ids, entry-major ([entry][query]: the lanes of a
-    // half-wave, one query each, touch 32 consecutive words); fill counts; liked-item rings; the two counters
-    static constexpr int SEL_S = PD * TILEB / 4;
+    // half-wave, one query each, touch 32 consecutive words); fill counts; liked-item rings; the progress words
+    static constexpr int SEL_S = PD * IMGB / 4;
     static constexpr int SEL_I = SEL_S + CAP * NQ;
     static constexpr int CNT = SEL_I + CAP * NQ;
     static constexpr int RINGS = CNT + NQ;
     static constexpr int SYNC = RINGS + NQ * RING;
-    static constexpr int SYNC_WORDS = 32;  // per wavefront: item images stored, item images read
-    static_assert(NW <= 16, "progress words");
+    static constexpr int SYNC_WORDS = 32;  // [0, 8): images landed per wavefront; [8, 16): images read
+    static_assert(NW <= 8, "progress words");
     static constexpr size_t BYTES = (size_t)(SYNC + SYNC_WORDS) * 4;
-    static_assert(PD >= 3, "three item images are staged ahead of the sweep");
     static constexpr int LIMIT = CAP - 16;  // entries a compaction may leave (at least k)
     static_assert(CAP % 2 == 0 && LIMIT >= TOPK_PLANE_KMAX && LIMIT <= 32, "buffer size");
 };
@@ -282,10 +294,20 @@ __device__ __forceinline__ int tk_compact_all(float* sel_s, int* sel_i, int* cnt
     return total;
 }
 
+// s_waitcnt vmcnt(N) for a wave-uniform N in 0 .. 3 (the instruction takes an immediate).
+__device__ __forceinline__ void tk_wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    }
+}
+
 template <int F, int NW, int CAP, int PD>
 __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const float* __restrict__ Q, int64_t nq, const float* __restrict__ Y, int64_t ni,
-    const uint32_t* __restrict__ planes, const uint32_t* __restrict__ ymax_bits,
+    const uint32_t* __restrict__ planes, const float* __restrict__ tile_norm, const uint32_t* __restrict__ ymax_bits,
     const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices,
     const int32_t* __restrict__ order, int k, int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
     int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
@@ -295,6 +317,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     constexpr int BI = TOPK_BI;
     constexpr int NQ = L::NQ;
     constexpr int RING = L::RING;
+    constexpr int D = PD - 2;  // images requested ahead of the tile being multiplied
+    static_assert(D >= 2 && L::NPW <= 3, "staging depth");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ybuf = reinterpret_cast<char*>(smem);
@@ -303,8 +327,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     int* cnt = reinterpret_cast<int*>(smem + L::CNT);
     int* rings = reinterpret_cast<int*>(smem + L::RINGS);
     int* sync = reinterpret_cast<int*>(smem + L::SYNC);
-    int* staged = sync;        // [w]: wavefront w has stored its share of the images of the tiles below this number
-    int* read_done = sync + 16;  // [w]: wavefront w has finished the matrix phase of the tiles below this number
+    int* staged = sync;         // [w]: the shares of wavefront w of the images of the tiles below this number are in LDS
+    int* read_done = sync + 8;  // [w]: wavefront w has its operands of the tiles below this number in registers
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -315,12 +339,11 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const int64_t ug = (int64_t)blockIdx.x * NQ + q;
     const bool uv = ug < nq;
 
-    if (tid < L::SYNC_WORDS) sync[tid] = tid < 16 ? 3 : 0;  // tiles 0 to 2 are staged before the sweep
     if (h == 0) cnt[q] = 0;
 
-    // B operands: query row ug, factors 16*s + 8*h .. + 7, as two bf16 planes; and the margin of the query
+    // B operands: query row ug, factors 16*s + 8*h .. + 7, as two bf16 planes; and the margins of the query
     tk_u32x4 qh[KS], qm[KS];
-    float marg;
+    float marg, cmarg;
     {
         const float* qr = Q + (uv ? ug : 0) * F + 8 * h;
         float n2 = 0.f;
@@ -342,6 +365,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         // the second term: at least the absolute error that products in the denormal range can add
         marg = (qn > 0.f && ymax > 0.f) ? 2.f * topk_eps_coef<F>() * qn * ymax + (float)(8 * F + 64) * 2.4e-38f
                                         : qn * ymax;
+        // per unit of a tile's largest row norm: what the two products with a mid plane can add to hi * hi
+        cmarg = topk_coarse_coef<F>() * qn;
     }
     // A zero margin means all scores are exactly zero on both pipes and only the order of the ids decides; a
     // margin that is not finite covers nothing.  Both go to the fp32 kernel.
@@ -352,8 +377,9 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
 
     // Liked-item filter: the lane of the first half-wave walks the (ascending) mask row of its query.  The row's
     // upcoming entries sit in a small LDS ring, [cur, tail) of the row, refilled four at a time by loads that are
-    // issued with the plane staging and committed a tile later -- the walk itself never waits for memory unless one
-    // query has more liked items in a tile than the ring delivers.
+    // issued when the walk has consumed entries and committed the next time it has something to do -- the walk
+    // itself never waits for memory unless one query has more liked items in a tile than the ring delivers.
+    // A tile in which no query of the wavefront has a liked item costs one compare.
     int* my_ring = rings + q * RING;
     const int32_t* mrow = mask_indices;
     int cur = 0, tail = 0, mlen = 0, pend_base = -1;
@@ -374,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     }
     auto mask_refill_issue = [&]() __attribute__((always_inline)) {
         // room for four more and something left to fetch; loads are unconditional (clamped) inside the branch
-        if (walker && tail < mlen && tail - cur <= RING - 4) {
+        if (walker && pend_base < 0 && tail < mlen && tail - cur <= RING - 4) {
             pend_base = tail;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             // The common case -- at most one liked item of a query in a tile -- without a loop and without
             // waiting for LDS: the entry after the one consumed is already in a register, the one after that is
             // requested now and not looked at before the next tile.
-            bool more = false;
+            bool more = nxt == 0x7fffffff && cur < mlen;  // not delivered when it was looked for: it may be by now
             if (nxt < lim) {
                 const int bit = nxt - i0;
                 if (bit >= 0) mw |= 1u << bit;
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
                 more = nxt < lim || (nxt == 0x7fffffff && cur < mlen);
             }
             if (__ballot(more) != 0ull) {
-                if (more && nxt == 0x7fffffff && cur < mlen) {  // not read when it was prefetched: it may be there by now
+                if (more && nxt == 0x7fffffff && cur < mlen) {
                     if (cur < tail)
                         nxt = my_ring[cur & (RING - 1)];
                     else
@@ -459,42 +485,43 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         return mw;
     };
 
-    // Item images: all wavefronts stage (global -> registers -> LDS); tile t + 2 goes to LDS during tile t, the
-    // loads of tile t + 3 are in flight meanwhile.
-    constexpr int NTS = 64 * NW;
-    constexpr int TILE_CH = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile
-    constexpr int NV = (TILE_CH + NTS - 1) / NTS;
-    tk_u32x4 pre[NV];
-    // Unconditional loads (a branch around a load makes the compiler wait for it on the spot): threads past
-    // the tile repeat its last chunk.
-    auto load_y = [&](int t) __attribute__((always_inline)) {
-        const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_CH;
+    // Item images: the hi plane of tile t goes to LDS slot t % PD by loads that write LDS directly, D tiles ahead of
+    // the products; every wavefront issues its share of the pieces of an image (piece p by wavefront p % NW).  The
+    // bytes of a piece are consecutive in LDS; each lane computes where its 16 of them come from (a chunk of the
+    // row padding repeats the row's last chunk).
+    constexpr int TILE_G = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile in the workspace
+    int soff[L::NPW];                               // source chunk of this lane, per piece of this wavefront
+    bool sval[L::NPW];
+    int npw = 0;  // pieces this wavefront issues per tile (wave-uniform)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            int e = tid + v * NTS;
-            e = e < TILE_CH ? e : TILE_CH - 1;
-            pre[v] = src[e];
+    for (int j = 0; j < L::NPW; ++j) {
+        const int piece = w + NW * j;
+        const int o = piece * 1024 + lane * 16;
+        const int row = o / L::ROWB;
+        int ch = (o % L::ROWB) / 16;
+        ch = ch < F8 ? ch : F8 - 1;
+        sval[j] = o < L::IMGB;
+        soff[j] = sval[j] ? row * F8 + ch : 0;
+        npw += piece < L::NPIECE ? 1 : 0;
+    }
+    auto dma = [&](int t) __attribute__((always_inline)) {
+        const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G;
+        char* slot = ybuf + (t % PD) * L::IMGB;
+#pragma unroll
+        for (int j = 0; j < L::NPW; ++j) {
+            const int piece = w + NW * j;
+            if (piece < L::NPIECE && sval[j]) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + soff[j]),
+                    (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+            }
         }
     };
-    auto store_y = [&](char* ytile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            int e = tid + v * NTS;
-            e = e < TILE_CH ? e : TILE_CH - 1;  // duplicates write the same values
-            const int row = e / F8;             // plane * 32 + item
-            const int kc = e % F8;
-            *reinterpret_cast<tk_u32x4*>(ytile + row * L::ROWB + 16 * kc) = pre[v];
-        }
-    };
-    // the caller guarantees at least two tiles; a tile past the last one repeats it (its image is never read)
-    load_y(0);
-    store_y(ybuf);
-    load_y(1);
-    store_y(ybuf + L::TILEB);
-    load_y(ntile > 2 ? 2 : ntile - 1);
-    store_y(ybuf + 2 * L::TILEB);
-    load_y(ntile > 3 ? 3 : ntile - 1);
-    __syncthreads();  // tiles 0 to 2 are staged, the progress words and fill counts are set
+    for (int t = 0; t < D; ++t)
+        if (t < ntile) dma(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid < L::SYNC_WORDS) sync[tid] = tid < 8 ? (D < ntile ? D : ntile) : 0;
+    __syncthreads();  // tiles 0 to D - 1 are staged, the progress words and fill counts are set
 
     // One candidate: reserve a slot of the query's buffer and fill it; false: the buffer is full.
     auto append = [&](float s, int item) __attribute__((always_inline)) -> bool {
@@ -505,88 +532,98 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         }
         return pos < CAP;
     };
-
-    // The matrix instructions of a tile are issued one tile ahead, between the steps of the selection over the
-    // previous tile's scores: the matrix pipe works on tile t + 1 while the vector and scalar units, the LDS and
-    // the branches of this same wavefront deal with tile t.
-    f32x16 acc0, acc1;
-    // A operands (item c of the tile, both planes) are fetched two k-steps ahead: the wait in front of a k-step's
-    // matrix instructions is for every LDS access in flight (the appends in between leave the compiler no
-    // other choice), so the newest fetch must be old by then
-    tk_u32x4 ya[3][TOPK_NPLANES];
-    const char* yb = ybuf + c * L::ROWB + 16 * h;
-    auto fetch = [&](int s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < TOPK_NPLANES; ++p) ya[s % 3][p] = *reinterpret_cast<const tk_u32x4*>(yb + p * L::PLANEB + 32 * s);
-    };
-    auto kstep = [&](int s) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        const tk_u32x4(&a)[TOPK_NPLANES] = ya[s % 3];
-        // mid * mid is below 2^-18 of |q_k y_k| and left to the margin; the first use of an accumulator starts
-        // it from zero (an operand of the instruction, not a register fill)
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (s & 1) {
-            acc1 = tk_mma(a[0], qh[s], acc1);  // hi hi
-            acc0 = tk_mma(a[1], qh[s], acc0);  // mid hi
-            acc1 = tk_mma(a[0], qm[s], acc1);  // hi mid
-        } else {
-            acc0 = tk_mma(a[0], qh[s], s == 0 ? zero : acc0);
-            acc1 = tk_mma(a[1], qh[s], s == 0 ? zero : acc1);
-            acc0 = tk_mma(a[0], qm[s], acc0);
+    auto compact = [&]() __attribute__((always_inline)) {
+        bool over;
+        tk_compact_all<CAP, NQ, L::LIMIT>(sel_s, sel_i, cnt, q, h, k, marg, thr, over);
+        if (over) {
+            ovf = true;
+            thr = INFINITY;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < KS) fetch(s + 2);
-        __builtin_amdgcn_sched_barrier(0);
     };
-    // k-step s goes in front of selection step ceil(16 s / KS)
-    auto ksteps_before = [&](int i) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            if ((16 * s + KS - 1) / KS == i) kstep(s);
-    };
-    fetch(0);
-    if (KS > 1) fetch(1);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) kstep(s);
-    if (lane == 0) tk_store_release(read_done + w, 1);
 
-    float sc[16];
+    // A operands: item c of the tile, hi plane
+    tk_u32x4 ya[KS];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const char* yb = ybuf + (t % PD) * L::IMGB + c * L::ROWB + 16 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ya[s] = *reinterpret_cast<const tk_u32x4*>(yb + 32 * s);
+    };
+    // lane l < 8 looks at the images landed of wavefront l, lane 8 + l at the images read of wavefront l
+    const int* my_word = sync + (lane < 16 ? lane : 0);
+    const int need_off = lane < 8 ? 1 : D - PD + 1;
+
+    // One tile.  The sweep multiplies the hi planes only (a third of the products) and looks at the largest of a
+    // lane's sixteen sums: what the two products with a mid plane can add is bounded by cmarg times the tile's
+    // largest row norm, so where sum + bound stays at or below the entry threshold for every query of the
+    // wavefront, no score of the tile can enter a buffer and the tile is done.  Otherwise the other two
+    // products follow (the mid plane of the tile comes straight from the workspace, which the cache holds: the
+    // image in LDS is the hi plane) and the scores go through the selection.
     for (int t = 0; t < ntile; ++t) {
         const int i0 = t * BI;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sc[i] = acc0[i] + acc1[i];
-        if (t == ntile - 1) {  // rows past the last item
-            const int left = (int)(ni - i0) - 4 * h;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[i] = tk_rowpos(i) < left ? sc[i] : -INFINITY;
+        // the image of tile t is complete, and the slot of tile t + D is free: everybody has the operands of
+        // the tile that was there in registers
+        {
+            const int need = t + need_off;
+            while (__ballot(lane < 16 && (lane & 7) < NW && tk_load_acquire(my_word) < need) != 0ull)
+                __builtin_amdgcn_s_sleep(1);
         }
-        // the next tile (after the last one: the last one again, for nothing); every wavefront has stored its
-        // share of its image
-        const int tn = t + 1 < ntile ? t + 1 : t;
-        if (tn >= 3) tk_wait_all<NW>(staged, tn + 1, lane);
-        yb = ybuf + (tn % PD) * L::TILEB + c * L::ROWB + 16 * h;
-        fetch(0);
-        if (KS > 1) fetch(1);
+        if (t + D < ntile) dma(t + D);
+        fetch(t);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc = zero;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = tk_mma(ya[s], qh[s], acc);
+        // this wavefront's pieces of the image of tile t + D - 1 have landed (those of tile t + D may be on their
+        // way), and its operands of tile t are in registers
+        if (npw > 0) tk_wait_vm(t + D < ntile ? npw : 0);
+        asm volatile("" ::: "memory");
+        if (lane == 0) {
+            const int landed = t + D < ntile ? t + D : ntile;
+            __hip_atomic_store(staged + w, landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(read_done + w, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+
+        float best = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])), fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
+        best = fmaxf(best, fmaxf(fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])),
+                                 fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]))));
+        const float tn = tile_norm[t];
+        const bool look = fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr;
 
         // liked items of the tile (walker lanes)
-        mask_refill_commit();
-        const unsigned mw = walk_tile(i0);
+        unsigned mw = 0u;
+        if (__ballot(nxt < i0 + BI || (nxt == 0x7fffffff && cur < mlen)) != 0ull) {
+            mask_refill_commit();
+            mw = walk_tile(i0);
+            mask_refill_issue();
+        }
 
-        float best4[4];  // of the four groups of four scores (items 8 g + 4 h .. + 3 of the tile)
+        if (__ballot(look) != 0ull) {
+            tk_u32x4 ym[KS];
+            const tk_u32x4* mp = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G + BI * F8 + c * F8 + h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) best4[g] = fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3]));
-        const float best = fmaxf(fmaxf(best4[0], best4[1]), fmaxf(best4[2], best4[3]));
-        unsigned fail = 0u;
-        if (__ballot(best > thr) != 0ull) {
+            for (int s = 0; s < KS; ++s) ym[s] = mp[2 * s];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = tk_mma(ya[s], qm[s], acc);  // hi mid
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = tk_mma(ym[s], qh[s], acc);  // mid hi
+            // mid * mid is below 2^-16 of |q| |y| and left to the margin
+            float sc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = acc[i];
+            if (t == ntile - 1) {  // rows past the last item
+                const int left = (int)(ni - i0) - 4 * h;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc[i] = tk_rowpos(i) < left ? sc[i] : -INFINITY;
+            }
             // liked bits of this lane's 16 items: bit tk_rowpos(i)
             unsigned liked = 0u;
             if (mask_indptr != nullptr) liked = (unsigned)__builtin_amdgcn_ds_bpermute(c << 2, (int)mw) >> (4 * h);
+            unsigned fail = 0u;
             // candidates are few: a group of four scores is looked at only where its best beats the threshold
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int i = 4 * g; i < 4 * g + 4; ++i) ksteps_before(i);
-                if (best4[g] > thr) {
+                const float best4 = fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3]));
+                if (best4 > thr) {
 #pragma unroll
                     for (int i = 4 * g; i < 4 * g + 4; ++i) {
                         if (sc[i] > thr && !((liked >> tk_rowpos(i)) & 1u)) {
@@ -595,61 +632,34 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
                     }
                 }
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) kstep(s);
-        }
-        if (lane == 0) tk_store_release(read_done + w, tn + 1);  // this wavefront is done with the image of tile tn
-
-        // Buffers that were full: compact (every query of the wavefront, which raises all thresholds) and offer
-        // the candidates that were turned away again.  A second compaction covers a tile whose candidates
-        // alone overfill the space a compaction leaves; after that the query is given up.
-        // A compaction stops a wavefront for a few thousand cycles, more than the image ring absorbs, so the others
-        // end up waiting for it; at the tiles of a schedule that all wavefronts share (fill grows with the
-        // logarithm of the tile number: powers of two) every wavefront compacts, and the forced ones become rare.
-        auto compact = [&]() __attribute__((always_inline)) {
-            bool over;
-            tk_compact_all<CAP, NQ, L::LIMIT>(sel_s, sel_i, cnt, q, h, k, marg, thr, over);
-            if (over) {
-                ovf = true;
-                thr = INFINITY;
-            }
-        };
-        bool fresh = false;  // compacted since the last candidate was turned away
-        if (t >= 2 && (t & (t - 1)) == 0) {
-            compact();
-            fresh = true;
-        }
-        int offers = 0;
-        while (__ballot(fail != 0u) != 0ull) {
-            if (offers == 2) {
-                if (fail != 0u) {
-                    ovf = true;
-                    thr = INFINITY;
+            // Buffers that were full: compact (every query of the wavefront, which raises all thresholds) and
+            // offer the candidates that were turned away again.  A second compaction covers a tile whose
+            // candidates alone overfill the space a compaction leaves; after that the query is given up.
+            int offers = 0;
+            while (__ballot(fail != 0u) != 0ull) {
+                if (offers == 2) {
+                    if (fail != 0u) {
+                        ovf = true;
+                        thr = INFINITY;
+                    }
+                    break;
                 }
-                break;
-            }
-            ++offers;
-            if (!fresh) compact();
-            fresh = false;
-            const unsigned again = fail;
-            fail = 0u;
+                ++offers;
+                compact();
+                const unsigned again = fail;
+                fail = 0u;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (((again >> i) & 1u) && sc[i] > thr) {
-                    if (!append(sc[i], i0 + tk_rowpos(i) + 4 * h)) fail |= 1u << i;
+                for (int i = 0; i < 16; ++i) {
+                    if (((again >> i) & 1u) && sc[i] > thr) {
+                        if (!append(sc[i], i0 + tk_rowpos(i) + 4 * h)) fail |= 1u << i;
+                    }
                 }
             }
         }
-
-        if (t + 3 < ntile) {
-            // the image that tile t + 3 replaces was that of tile t + 3 - PD: everybody must be done reading it
-            if (t + 4 - PD >= 1) tk_wait_all<NW>(read_done, t + 4 - PD, lane);
-            store_y(ybuf + ((t + 3) % PD) * L::TILEB);
-            if (lane == 0) tk_store_release(staged + w, t + 4);
-            load_y(t + 4 < ntile ? t + 4 : ntile - 1);
-        }
-        mask_refill_issue();
+        // Thresholds only rise at a compaction.  While they are far from their final values (the first tiles
+        // of a sweep) every wavefront compacts on a schedule the whole workgroup shares: the powers of two -- the
+        // fill of a buffer grows with the logarithm of the tile number.
+        if (t >= 2 && (t & (t - 1)) == 0) compact();
     }
 
     // ---- margin set -> exact scores -> the k best, for the 32 queries of the wavefront
@@ -758,17 +768,18 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
     uint32_t* ymax_bits = reinterpret_cast<uint32_t*>(base);
     int32_t* qcount = reinterpret_cast<int32_t*>(base + 4);
     int32_t* qlist = reinterpret_cast<int32_t*>(base + lay.qlist_off);
+    float* tile_norm = reinterpret_cast<float*>(base + lay.tnorm_off);
     uint32_t* planes = reinterpret_cast<uint32_t*>(base + lay.planes_off);
     const int ntile = (int)((ni + TOPK_BI - 1) / TOPK_BI);
 
     MIREC_HIP(hipMemsetAsync(base, 0, 256, stream));
     hipLaunchKernelGGL((topk_split_items_kernel<F>), dim3((unsigned)ntile), dim3(32 * (F / 8)), 0, stream, Y, ni,
-                       item_order, planes, ymax_bits);
+                       item_order, planes, tile_norm, ymax_bits);
     MIREC_LAUNCH_CHECK();
     const int64_t blocks = (nq + L::NQ - 1) / L::NQ;
     // with an order the sweep meets positions, and the filter rows it walks are those renumbered to positions
     hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream, Q, nq,
-                       Y, ni, planes, ymax_bits, mask_indptr, item_order != nullptr ? mask_positions : mask_indices,
+                       Y, ni, planes, tile_norm, ymax_bits, mask_indptr, item_order != nullptr ? mask_positions : mask_indices,
                        item_order, k, out_ids, out_scores, qlist, qcount);
     MIREC_LAUNCH_CHECK();
     // the queries handed over (none, as a rule): the fp32 kernel in list mode, sized for the worst case
@@ -789,7 +800,7 @@ int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const in
                           "mirec_topk: workspace of %zu bytes given, mirec_topk_workspace_bytes asks for %zu", ws_bytes,
                           topk_workspace_layout(nq, ni, F).bytes);
             MIREC_REQUIRE(((uintptr_t)ws & 255) == 0, MIREC_E_INVALID, "mirec_topk: workspace must be 256-byte aligned");
-            return launch_topk_planes_cfg<F, 8, 48, 3>(Q, nq, Y, ni, mask_indptr, mask_indices, item_order, mask_positions,
+            return launch_topk_planes_cfg<F, 8, 48, 6>(Q, nq, Y, ni, mask_indptr, mask_indices, item_order, mask_positions,
                                                        k, out_ids, out_scores, ws, stream);
         }
     }

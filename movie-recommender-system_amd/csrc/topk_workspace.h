@@ -2,6 +2,7 @@
 //
 //   [0, 256)            header: u32 bits of max ||y|| at byte 0, i32 length of the query list at byte 4
 //   [256, 256 + Lq)     query list: int32 per query (Lq = 4*nq rounded up to 256)
+//   [.., .. + Ln)       largest row norm of every item tile: float per tile (Ln rounded up to 256)
 //   [.., .. + Lp)       item factors split into two bf16 planes (hi, mid), tile by tile:
 //                       [tile][plane][32 items][f] bf16, rows past the last item zero
 #pragma once
@@ -18,15 +19,16 @@ inline bool topk_planes_supported(int f, int k) {
 }
 
 struct TopkWorkspace {
-    size_t qlist_off, planes_off, bytes;
+    size_t qlist_off, tnorm_off, planes_off, bytes;
 };
 
 inline TopkWorkspace topk_workspace_layout(int64_t nq, int64_t ni, int f) {
     TopkWorkspace w;
     w.qlist_off = 256;
     const size_t lq = ((size_t)nq * 4 + 255) / 256 * 256;
-    w.planes_off = w.qlist_off + lq;
     const size_t ntile = (size_t)((ni + 31) / 32);
+    w.tnorm_off = w.qlist_off + lq;
+    w.planes_off = w.tnorm_off + (ntile * 4 + 255) / 256 * 256;
     w.bytes = w.planes_off + ntile * TOPK_NPLANES * 32 * (size_t)f * 2;
     return w;
 }

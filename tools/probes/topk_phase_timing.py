@@ -1,7 +1,9 @@
 """Phase timing of the bf16-plane top-K kernel (library built with -DMIREC_DEBUG_TIMING for topk_inst_3.hip).
 
-usage: topk_phase_timing.py <libmirec variant>
-Prints, per tile and per wavefront, the mean cycle counts of the sections of the sweep.
+usage: topk_phase_timing.py <libmirec variant> [ALS iterations]
+Prints, per tile and per wavefront, the mean cycle counts of the sections of the sweep: with random factors, or --
+with a number of iterations -- with the benchmark's factors trained that long, the items in their own order and by
+descending interactions.
 """
 import ctypes
 import os
@@ -17,16 +19,29 @@ dev = torch.device("cuda", 0)
 U, I, F = 1_000_000, 27_000, 128
 indptr, indices, data = synth.interactions_torch(42, U, I, 50.0, dev)
 Cui = E.DeviceCSR(indptr, indices, data, (U, I))
-g = torch.Generator(device=dev)
-g.manual_seed(1)
-X = torch.randn((U, F), device=dev, generator=g) * 0.3
-Y = torch.randn((I, F), device=dev, generator=g) * 0.3
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if iters:
+    import numpy as np
+    rs = np.random.RandomState(42)
+    X = E.pad_factors(rs.rand(U, F).astype(np.float32) * 0.01, F, dev)
+    Y = E.pad_factors(rs.rand(I, F).astype(np.float32) * 0.01, F, dev)
+    eng = E.AlsEngine(E.DeviceCSR(indptr, indices, data * 40.0, (U, I)), None, X, Y, 0.01, 3)
+    for _ in range(iters):
+        eng.iteration()
+    torch.cuda.synchronize()
+else:
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    X = torch.randn((U, F), device=dev, generator=g) * 0.3
+    Y = torch.randn((I, F), device=dev, generator=g) * 0.3
+ordered = E.DeviceCSR(indptr, indices, data, (U, I))
+ordered.build_order()
 lib = _lib.require()
 out = (ctypes.c_ulonglong * 16)()
 NAMES = ["scores out of the accumulators", "wait: next image staged", "liked-item walk",
          "selection + next tile's matrix instructions", "compactions + second offers", "wait: old image read",
          "staging"]
-for mask in (Cui, None):
+for mask in (Cui, ordered, None):
     E.topk(X, Y, 20, mask)
     torch.cuda.synchronize()
     lib.mirec_topk_debug_read(out, 1)
@@ -38,6 +53,6 @@ for mask in (Cui, None):
     lib.mirec_topk_debug_read(out, 1)
     v = list(out)
     nt = max(v[8], 1)
-    print("filter=%s %.2f ms; per tile:" % (mask is not None, e0.elapsed_time(e1)),
+    print("filter=%s ordered=%s %.2f ms; per tile:" % (mask is not None, mask is ordered, e0.elapsed_time(e1)),
           "; ".join("%s %.0f" % (n, v[i] / nt) for i, n in enumerate(NAMES)),
           "; total %.0f; final stage %.0f cycles per workgroup" % (sum(v[:7]) / nt, v[7] / max(nt / ((I + 31) // 32), 1)))
