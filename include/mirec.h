@@ -217,31 +217,38 @@ int mirec_topk_small(const float* Q, int64_t nq, const float* Y, int64_t ni, int
                      int32_t* out_ids, float* out_scores, void* ws, size_t ws_bytes, mirec_stream_t stream);
 
 /* mirec_topk with the items swept in a given order.  Results are those of mirec_topk, bit for
- * bit, whatever the order: the order only decides how much selection work the all-users sweep
- * has -- least when the items most queries score highest come first, which an item's number of
+ * bit, whatever the order: the order only decides how much work the all-users sweep has --
+ * least when the items most queries score highest come first, which an item's number of
  * interactions predicts well (a wavefront of 32 queries then finds nothing to look at in about
- * nineteen item tiles out of twenty, against one in two).  The all-users pass behind
- * `model.recommend` over every user of `train_matrix`
+ * nineteen item tiles out of twenty, against one in two, and skips two thirds of their
+ * products).  The all-users pass behind `model.recommend` over every user of `train_matrix`
  * (recommenders/als_recommender.py:181-186 in a loop; als/als.py:177-185 for evaluation).
- *   item_order      int32[ni]: position -> item, a permutation of 0 .. ni-1
- *   mask_positions  int32[nnz]: with a filter, its rows (same mask_indptr) as positions of
- *                   item_order, ascending; mask_indices is still needed (queries the sweep hands
- *                   to the fp32 kernel use it)
- * mirec_topk_order_build fills both from the filter matrix, once per matrix and not per model:
- * items by descending number of stored entries, ties by ascending index; needs
- * mirec_topk_order_workspace_bytes(ni) of scratch and ni <= MIREC_TOPK_ORDER_MAX_ITEMS.
- * Without a filter any permutation may be given (e.g. by descending norm).  Entries of either
- * array outside 0 .. ni-1 are clamped, never dereferenced; an item_order that is not a
- * permutation gives unspecified results.  Where the sweep kernel does not run (no workspace,
- * f not a multiple of 16 or above 128, k > 24, fewer than 64 items) the order is ignored. */
+ *   item_order   int32[ni]: position -> item, a permutation of 0 .. ni-1
+ *   mask_blocks  with a filter: int32 pairs (position, row set), one list per block of 32 filter
+ *                rows -- the positions any row of the block holds, ascending, bit r of the row set
+ *                = row 32 b + r holds it; the list of block b starts at pair mask_indptr[32 b]
+ *   block_len    int32 per block: pairs in its list
+ * mask_indptr / mask_indices stay the filter in item numbering (queries the sweep hands to the
+ * fp32 kernel use it).  Query 0 must be the first row of a block: to score rows [a, b) of the
+ * matrix pass mask_indptr + a and block_len + a / 32 with a % 32 == 0.
+ * mirec_topk_order_build fills all three from the filter matrix, once per matrix and not per
+ * model: items by descending number of stored entries, ties by ascending index; mask_blocks has
+ * room for nnz pairs (8 nnz bytes, 8-byte aligned), block_len for ceil(nrows / 32) entries; it
+ * needs mirec_topk_order_workspace_bytes(ni) of scratch and ni <= MIREC_TOPK_ORDER_MAX_ITEMS.
+ * Without a filter any permutation may be given (e.g. by descending norm) and the two arrays are
+ * NULL.  Entries of item_order outside 0 .. ni-1 are clamped, never dereferenced; an item_order
+ * that is not a permutation, or lists that do not belong to it, give unspecified results.  Where
+ * the sweep kernel does not run (no workspace, f not a multiple of 16 or above 128, k > 24,
+ * fewer than 64 items) the order is ignored. */
 #define MIREC_TOPK_ORDER_MAX_ITEMS 262144
 size_t mirec_topk_order_workspace_bytes(int64_t ni);
 int mirec_topk_order_build(const int64_t* mask_indptr, const int32_t* mask_indices, int64_t nrows, int64_t nnz,
-                           int64_t ni, int32_t* item_order, int32_t* mask_positions, void* ws, size_t ws_bytes,
-                           mirec_stream_t stream);
+                           int64_t ni, int32_t* item_order, int32_t* mask_blocks, int32_t* block_len, void* ws,
+                           size_t ws_bytes, mirec_stream_t stream);
 int mirec_topk_ordered(const float* Q, int64_t nq, const float* Y, int64_t ni, int f, const int64_t* mask_indptr,
-                       const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_positions, int k,
-                       int32_t* out_ids, float* out_scores, void* ws, size_t ws_bytes, mirec_stream_t stream);
+                       const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_blocks,
+                       const int32_t* block_len, int k, int32_t* out_ids, float* out_scores, void* ws,
+                       size_t ws_bytes, mirec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * LightFM representations (lightfm `compute_representation`, reached from

@@ -49,8 +49,8 @@ SIGNATURES = {
     "mirec_topk_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mirec_topk": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "mirec_topk_order_workspace_bytes": (_sz, [_i64]),
-    "mirec_topk_order_build": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "mirec_topk_ordered": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
+    "mirec_topk_order_build": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mirec_topk_ordered": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "mirec_topk_small_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "mirec_topk_small": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "mirec_lightfm_repr": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _int, _vp, _int, _int, _int, _int, _vp]),

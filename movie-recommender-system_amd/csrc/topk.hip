@@ -6,9 +6,9 @@
 namespace mirec {
 template <int F>
 int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
-                const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_positions,
-                const float* y_norm, const float* q_norm, int k, int32_t* out_ids, float* out_scores, void* ws,
-                size_t ws_bytes, hipStream_t stream);
+                const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_blocks,
+                const int32_t* block_len, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
+                float* out_scores, void* ws, size_t ws_bytes, hipStream_t stream);
 }  // namespace mirec
 
 extern "C" size_t mirec_topk_workspace_bytes(int64_t nq, int64_t ni, int f, int k) {
@@ -18,8 +18,8 @@ extern "C" size_t mirec_topk_workspace_bytes(int64_t nq, int64_t ni, int f, int 
 
 static int topk_entry(const char* who, const float* Q, int64_t nq, const float* Y, int64_t ni, int f,
                       const int64_t* mask_indptr, const int32_t* mask_indices, const int32_t* item_order,
-                      const int32_t* mask_positions, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
-                      float* out_scores, void* ws, size_t ws_bytes, hipStream_t stream) {
+                      const int32_t* mask_blocks, const int32_t* block_len, const float* y_norm, const float* q_norm,
+                      int k, int32_t* out_ids, float* out_scores, void* ws, size_t ws_bytes, hipStream_t stream) {
     MIREC_REQUIRE(nq >= 0 && ni >= 0, MIREC_E_INVALID, "%s: negative size", who);
     MIREC_REQUIRE(k >= 1, MIREC_E_INVALID, "%s: k must be >= 1 (got %d)", who, k);
     MIREC_REQUIRE(k <= 224, MIREC_E_UNSUPPORTED, "%s: k = %d exceeds the supported maximum of 224", who, k);
@@ -28,13 +28,14 @@ static int topk_entry(const char* who, const float* Q, int64_t nq, const float* 
     MIREC_REQUIRE(ni < ((int64_t)1 << 31), MIREC_E_UNSUPPORTED, "%s: more than 2^31 items", who);
     MIREC_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)Q & 3) == 0, MIREC_E_INVALID, "%s: Y must be 16-byte aligned",
                   who);
-    MIREC_REQUIRE(item_order == nullptr || mask_indptr == nullptr || mask_positions != nullptr, MIREC_E_INVALID,
-                  "%s: an item order with a filter needs the filter rows in positions of that order "
+    MIREC_REQUIRE(item_order == nullptr || mask_indptr == nullptr || (mask_blocks != nullptr && block_len != nullptr),
+                  MIREC_E_INVALID,
+                  "%s: an item order with a filter needs the filter as lists per 32 rows in positions of that order "
                   "(mirec_topk_order_build)", who);
 #define MIREC_TOPK_CASE(FW)                                                                                     \
     case FW:                                                                                                    \
-        return mirec::launch_topk<FW>(Q, nq, Y, ni, mask_indptr, mask_indices, item_order, mask_positions, y_norm, \
-                                      q_norm, k, out_ids, out_scores, ws, ws_bytes, stream);
+        return mirec::launch_topk<FW>(Q, nq, Y, ni, mask_indptr, mask_indices, item_order, mask_blocks, block_len, \
+                                      y_norm, q_norm, k, out_ids, out_scores, ws, ws_bytes, stream);
     switch (f) {
         MIREC_TOPK_CASE(8)
         MIREC_TOPK_CASE(16)
@@ -56,8 +57,8 @@ extern "C" int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni
                           const int64_t* mask_indptr, const int32_t* mask_indices, const float* y_norm,
                           const float* q_norm, int k, int32_t* out_ids, float* out_scores, void* ws, size_t ws_bytes,
                           mirec_stream_t stream_) {
-    return topk_entry("mirec_topk", Q, nq, Y, ni, f, mask_indptr, mask_indices, nullptr, nullptr, y_norm, q_norm, k,
-                      out_ids, out_scores, ws, ws_bytes, (hipStream_t)stream_);
+    return topk_entry("mirec_topk", Q, nq, Y, ni, f, mask_indptr, mask_indices, nullptr, nullptr, nullptr, y_norm, q_norm,
+                      k, out_ids, out_scores, ws, ws_bytes, (hipStream_t)stream_);
 }
 
 // mirec_topk with the items swept in a caller-given order: the same results, less selection work when the order
@@ -66,8 +67,8 @@ extern "C" int mirec_topk(const float* Q, int64_t nq, const float* Y, int64_t ni
 // not looked at.
 extern "C" int mirec_topk_ordered(const float* Q, int64_t nq, const float* Y, int64_t ni, int f,
                                   const int64_t* mask_indptr, const int32_t* mask_indices, const int32_t* item_order,
-                                  const int32_t* mask_positions, int k, int32_t* out_ids, float* out_scores, void* ws,
-                                  size_t ws_bytes, mirec_stream_t stream_) {
-    return topk_entry("mirec_topk_ordered", Q, nq, Y, ni, f, mask_indptr, mask_indices, item_order, mask_positions,
-                      nullptr, nullptr, k, out_ids, out_scores, ws, ws_bytes, (hipStream_t)stream_);
+                                  const int32_t* mask_blocks, const int32_t* block_len, int k, int32_t* out_ids,
+                                  float* out_scores, void* ws, size_t ws_bytes, mirec_stream_t stream_) {
+    return topk_entry("mirec_topk_ordered", Q, nq, Y, ni, f, mask_indptr, mask_indices, item_order, mask_blocks,
+                      block_len, nullptr, nullptr, k, out_ids, out_scores, ws, ws_bytes, (hipStream_t)stream_);
 }

@@ -2,9 +2,9 @@
 
 namespace mirec {
 template int launch_topk<8>(const float*, int64_t, const float*, int64_t, const int64_t*, const int32_t*,
-                              const int32_t*, const int32_t*, const float*, const float*, int, int32_t*, float*, void*, size_t, hipStream_t);
+                              const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, int32_t*, float*, void*, size_t, hipStream_t);
 template int launch_topk<16>(const float*, int64_t, const float*, int64_t, const int64_t*, const int32_t*,
-                              const int32_t*, const int32_t*, const float*, const float*, int, int32_t*, float*, void*, size_t, hipStream_t);
+                              const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, int32_t*, float*, void*, size_t, hipStream_t);
 template int launch_topk<24>(const float*, int64_t, const float*, int64_t, const int64_t*, const int32_t*,
-                              const int32_t*, const int32_t*, const float*, const float*, int, int32_t*, float*, void*, size_t, hipStream_t);
+                              const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, int32_t*, float*, void*, size_t, hipStream_t);
 }  // namespace mirec

@@ -304,13 +304,17 @@ __device__ __forceinline__ void tk_wait_vm(int n) {
     }
 }
 
-template <int F, int NW, int CAP, int PD>
+// BLOCKS: the filter comes as one list per 32 queries (a wavefront's), sorted by position of the sweep, each entry
+// a position and the 32-bit set of the block's rows that hold it (mask_indices then points to those pairs and
+// block_len to the lists' lengths; the list of the block that starts at query row r begins at entry
+// mask_indptr[r]).  Otherwise the filter is the CSR rows themselves, ascending, one walked per query.
+template <int F, int NW, int CAP, int PD, bool BLOCKS>
 __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const float* __restrict__ Q, int64_t nq, const float* __restrict__ Y, int64_t ni,
     const uint32_t* __restrict__ planes, const float* __restrict__ tile_norm, const uint32_t* __restrict__ ymax_bits,
     const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices,
-    const int32_t* __restrict__ order, int k, int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
-    int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
+    const int32_t* __restrict__ block_len, const int32_t* __restrict__ order, int k, int32_t* __restrict__ out_ids,
+    float* __restrict__ out_scores, int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
     using L = TopkPlanesLds<F, NW, CAP, PD>;
     constexpr int KS = F / 16;  // MFMA k-steps
     constexpr int F8 = F / 8;   // 16-byte chunks per plane row
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     int cur = 0, tail = 0, mlen = 0, pend_base = -1;
     int nxt = 0x7fffffff, nxt2 = 0x7fffffff;  // the row's entries cur and cur + 1 (0x7fffffff: none, or not read yet)
     int rf[4] = {0, 0, 0, 0};
-    const bool walker = mask_indptr != nullptr && h == 0 && uv;
+    const bool walker = !BLOCKS && mask_indptr != nullptr && h == 0 && uv;
     if (walker) {
         const int64_t b = mask_indptr[ug];
         mrow = mask_indices + b;
@@ -481,6 +485,74 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
                     }
                 }
             }
+        }
+        return mw;
+    };
+
+    // The filter as a list per wavefront (BLOCKS): lane j holds entry 64 * chunk + j of the list -- its position
+    // and row set -- and the chunk after that waits in a second pair of registers; `cons` entries of the current
+    // chunk lie in tiles already swept.  Everything about the walk is the same for all lanes: a tile without
+    // a liked item costs one compare, and the loads of a chunk are coalesced and needed 64 entries later.
+    int bpos0 = 0x7fffffff, bpos1 = 0x7fffffff;
+    unsigned brm0 = 0u, brm1 = 0u;
+    int cons = 0, bnext = 0, blen = 0;
+    const int2* bent = nullptr;
+    unsigned* mwl = reinterpret_cast<unsigned*>(rings) + w * 32;  // liked bits of the wavefront's queries for one tile
+    auto block_load = [&](int first, int& pos, unsigned& rm) __attribute__((always_inline)) {
+        const int idx = first + lane;
+        const int2 e = bent[idx < blen ? idx : (blen > 0 ? blen - 1 : 0)];
+        pos = idx < blen ? e.x : 0x7fffffff;
+        rm = idx < blen ? (unsigned)e.y : 0u;
+    };
+    if constexpr (BLOCKS) {
+        if (mask_indptr != nullptr) {
+            const int64_t row0 = (int64_t)blockIdx.x * NQ + w * 32;  // first query of the wavefront
+            if (row0 < nq) {
+                bent = reinterpret_cast<const int2*>(mask_indices) + mask_indptr[row0];
+                blen = block_len[row0 >> 5];
+                if (blen > 0) {
+                    block_load(0, bpos0, brm0);
+                    block_load(64, bpos1, brm1);
+                }
+                bnext = 128;
+            }
+        }
+    }
+    // Liked bits of the tile [i0, i0 + 32) for this lane's query, or -- want == false -- only the step past them.
+    auto walk_blocks = [&](int i0, bool want) __attribute__((always_inline)) -> unsigned {
+        const int lim = i0 + BI;
+        bool any = false;
+        for (;;) {
+            const int nlt = __builtin_popcountll(__ballot(bpos0 < lim));  // the list is sorted: a prefix
+            if (nlt > cons) {
+                if (want) {
+                    if (!any) {
+                        if (lane < 32) mwl[lane] = 0u;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (lane >= cons && lane < nlt) {
+                        const unsigned bit = 1u << (bpos0 - i0);
+                        unsigned rm = brm0;
+                        while (rm != 0u) {
+                            atomicOr(mwl + __builtin_ctz(rm), bit);
+                            rm &= rm - 1u;
+                        }
+                    }
+                    any = true;
+                }
+                cons = nlt;
+            }
+            if (nlt < 64) break;
+            bpos0 = bpos1;
+            brm0 = brm1;
+            cons = 0;
+            block_load(bnext, bpos1, brm1);
+            bnext += 64;
+        }
+        unsigned mw = 0u;
+        if (any) {
+            __builtin_amdgcn_wave_barrier();
+            mw = mwl[c];
         }
         return mw;
     };
@@ -589,15 +661,21 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         const float tn = tile_norm[t];
         const bool look = fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr;
 
-        // liked items of the tile (walker lanes)
+        const bool second = __ballot(look) != 0ull;
+        // liked items of the tile: per query in the walker lanes, or (BLOCKS) in both lanes of a query's pair
         unsigned mw = 0u;
-        if (__ballot(nxt < i0 + BI || (nxt == 0x7fffffff && cur < mlen)) != 0ull) {
-            mask_refill_commit();
-            mw = walk_tile(i0);
-            mask_refill_issue();
+        if constexpr (BLOCKS) {
+            // the first entry not yet passed sits in lane `cons`
+            if (__builtin_amdgcn_readlane(bpos0, cons) < i0 + BI) mw = walk_blocks(i0, second);
+        } else {
+            if (__ballot(nxt < i0 + BI || (nxt == 0x7fffffff && cur < mlen)) != 0ull) {
+                mask_refill_commit();
+                mw = walk_tile(i0);
+                mask_refill_issue();
+            }
         }
 
-        if (__ballot(look) != 0ull) {
+        if (second) {
             tk_u32x4 ym[KS];
             const tk_u32x4* mp = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G + BI * F8 + c * F8 + h;
 #pragma unroll
@@ -617,7 +695,10 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             }
             // liked bits of this lane's 16 items: bit tk_rowpos(i)
             unsigned liked = 0u;
-            if (mask_indptr != nullptr) liked = (unsigned)__builtin_amdgcn_ds_bpermute(c << 2, (int)mw) >> (4 * h);
+            if constexpr (BLOCKS)
+                liked = mw >> (4 * h);
+            else if (mask_indptr != nullptr)
+                liked = (unsigned)__builtin_amdgcn_ds_bpermute(c << 2, (int)mw) >> (4 * h);
             unsigned fail = 0u;
             // candidates are few: a group of four scores is looked at only where its best beats the threshold
 #pragma unroll
@@ -751,15 +832,18 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
 
 template <int F, int NW, int CAP, int PD>
 static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
-                                  const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_positions,
-                                  int k, int32_t* out_ids, float* out_scores, void* ws, hipStream_t stream) {
+                                  const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_blocks,
+                                  const int32_t* block_len, int k, int32_t* out_ids, float* out_scores, void* ws,
+                                  hipStream_t stream) {
     using L = TopkPlanesLds<F, NW, CAP, PD>;
     static_assert(L::BYTES <= 160 * 1024, "top-K plane kernel: LDS image too large");
     static OncePerDevice once;  // idempotent; a race only repeats the call
     bool* attr_done = once.slot();
     MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
     if (!*attr_done) {
-        MIREC_HIP(hipFuncSetAttribute((const void*)topk_planes_kernel<F, NW, CAP, PD>,
+        MIREC_HIP(hipFuncSetAttribute((const void*)topk_planes_kernel<F, NW, CAP, PD, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
+        MIREC_HIP(hipFuncSetAttribute((const void*)topk_planes_kernel<F, NW, CAP, PD, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
         *attr_done = true;
     }
@@ -777,10 +861,16 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
                        item_order, planes, tile_norm, ymax_bits);
     MIREC_LAUNCH_CHECK();
     const int64_t blocks = (nq + L::NQ - 1) / L::NQ;
-    // with an order the sweep meets positions, and the filter rows it walks are those renumbered to positions
-    hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream, Q, nq,
-                       Y, ni, planes, tile_norm, ymax_bits, mask_indptr, item_order != nullptr ? mask_positions : mask_indices,
-                       item_order, k, out_ids, out_scores, qlist, qcount);
+    if (item_order != nullptr) {
+        // the sweep meets positions of the order; its filter is the lists per 32 queries, in positions
+        hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD, true>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream,
+                           Q, nq, Y, ni, planes, tile_norm, ymax_bits, mask_indptr, mask_blocks, block_len, item_order, k,
+                           out_ids, out_scores, qlist, qcount);
+    } else {
+        hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD, false>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream,
+                           Q, nq, Y, ni, planes, tile_norm, ymax_bits, mask_indptr, mask_indices, nullptr, nullptr, k, out_ids,
+                           out_scores, qlist, qcount);
+    }
     MIREC_LAUNCH_CHECK();
     // the queries handed over (none, as a rule): the fp32 kernel in list mode, sized for the worst case
     return launch_topk_fused<F>(Q, nq, Y, ni, mask_indptr, mask_indices, nullptr, nullptr, k, out_ids, out_scores, qlist,
@@ -791,17 +881,17 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
 // k > 24, for the similar-items mode (per-score divisions) and for tiny item sets the fp32 kernel runs alone.
 template <int F>
 int launch_topk(const float* Q, int64_t nq, const float* Y, int64_t ni, const int64_t* mask_indptr,
-                const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_positions,
-                const float* y_norm, const float* q_norm, int k, int32_t* out_ids, float* out_scores, void* ws,
-                size_t ws_bytes, hipStream_t stream) {
+                const int32_t* mask_indices, const int32_t* item_order, const int32_t* mask_blocks,
+                const int32_t* block_len, const float* y_norm, const float* q_norm, int k, int32_t* out_ids,
+                float* out_scores, void* ws, size_t ws_bytes, hipStream_t stream) {
     if constexpr (F % 16 == 0 && F <= 128) {
         if (ws != nullptr && y_norm == nullptr && q_norm == nullptr && topk_planes_supported(F, k) && ni >= 2 * TOPK_BI) {
             MIREC_REQUIRE(ws_bytes >= topk_workspace_layout(nq, ni, F).bytes, MIREC_E_INVALID,
                           "mirec_topk: workspace of %zu bytes given, mirec_topk_workspace_bytes asks for %zu", ws_bytes,
                           topk_workspace_layout(nq, ni, F).bytes);
             MIREC_REQUIRE(((uintptr_t)ws & 255) == 0, MIREC_E_INVALID, "mirec_topk: workspace must be 256-byte aligned");
-            return launch_topk_planes_cfg<F, 8, 48, 6>(Q, nq, Y, ni, mask_indptr, mask_indices, item_order, mask_positions,
-                                                       k, out_ids, out_scores, ws, stream);
+            return launch_topk_planes_cfg<F, 8, 48, 6>(Q, nq, Y, ni, mask_indptr, mask_indices, item_order, mask_blocks,
+                                                       block_len, k, out_ids, out_scores, ws, stream);
         }
     }
     return launch_topk_fused<F>(Q, nq, Y, ni, mask_indptr, mask_indices, y_norm, q_norm, k, out_ids, out_scores, nullptr,

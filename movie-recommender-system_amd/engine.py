@@ -77,14 +77,14 @@ class DeviceCSR:
         self.indptr, self.indices, self.data = indptr, indices, data
         self.shape = (int(shape[0]), int(shape[1]))
         self.nnz = int(indices.numel())
-        self.order = None   # (item_order, positions) once build_order has run: see there
+        self.order = None   # (item_order, blocks, block_len) once build_order has run: see there
 
     def build_order(self):
         """Prepare this matrix as the liked-item filter of all-users top-K passes: the items in descending number
-        of interactions, and every row renumbered to positions of that order and sorted.  ``topk`` then sweeps
-        the items in that order -- same results, about a tenth of the selection work.  Once per matrix (it does
-        not depend on the factors); row views made by ``rows`` share it.  Returns False, and changes nothing,
-        for catalogues too large for the row kernel's bitmap."""
+        of interactions, and the filter as one list per 32 rows (the queries of a wavefront) in positions of that
+        order.  ``topk`` then sweeps the items in that order -- same results, a fraction of the work.  Once per
+        matrix (it does not depend on the factors); row views made by ``rows`` share it.  Returns False, and
+        changes nothing, for catalogues too large for the list kernel."""
         lib = _lib.require()
         nu, ni = self.shape
         ws_bytes = int(lib.mirec_topk_order_workspace_bytes(ni))
@@ -92,19 +92,22 @@ class DeviceCSR:
             return self.order is not None
         dev = self.indices.device
         item_order = torch.empty(ni, dtype=torch.int32, device=dev)
-        positions = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)
+        blocks = torch.empty((max(self.nnz, 1), 2), dtype=torch.int32, device=dev)
+        block_len = torch.empty(max((nu + 31) // 32, 1), dtype=torch.int32, device=dev)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.mirec_topk_order_build(_ptr(self.indptr), _ptr(self.indices), nu, self.nnz, ni,
-                                              _ptr(item_order), _ptr(positions), _ptr(ws), ws_bytes, _stream_ptr()),
-                   "mirec_topk_order_build")
-        self.order = (item_order, positions)
+                                              _ptr(item_order), _ptr(blocks), _ptr(block_len), _ptr(ws), ws_bytes,
+                                              _stream_ptr()), "mirec_topk_order_build")
+        self.order = (item_order, blocks, block_len)
         return True
 
     def rows(self, a: int, b: int) -> "DeviceCSR":
         """Rows [a, b) as a view: the kernels index the row pointers by query and read absolute offsets, so
-        nothing is copied (not a matrix of its own: ``indptr`` does not start at 0)."""
+        nothing is copied (not a matrix of its own: ``indptr`` does not start at 0).  The view keeps the sweep
+        order when it starts at a block of 32 rows."""
         v = DeviceCSR(self.indptr[a:b + 1], self.indices, self.data, (b - a, self.shape[1]))
-        v.order = self.order
+        if self.order is not None and a % 32 == 0:
+            v.order = (self.order[0], self.order[1], self.order[2][a // 32:])
         return v
 
     @classmethod
@@ -469,10 +472,10 @@ def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = N
         if ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Q.device)
     if ws is not None and mask is not None and mask.order is not None and mask.shape[1] == ni:
-        item_order, positions = mask.order
+        item_order, blocks, block_len = mask.order
         _lib.check(lib.mirec_topk_ordered(_ptr(Q), nq, _ptr(Y), ni, f, _ptr(mask.indptr), _ptr(mask.indices),
-                                          _ptr(item_order), _ptr(positions), int(k), _ptr(ids), _ptr(scores),
-                                          _ptr(ws), ws_bytes, _stream_ptr()), "mirec_topk_ordered")
+                                          _ptr(item_order), _ptr(blocks), _ptr(block_len), int(k), _ptr(ids),
+                                          _ptr(scores), _ptr(ws), ws_bytes, _stream_ptr()), "mirec_topk_ordered")
         return ids, scores
     _lib.check(lib.mirec_topk(_ptr(Q), nq, _ptr(Y), ni, f, _ptr(None if mask is None else mask.indptr),
                               _ptr(None if mask is None else mask.indices), _ptr(y_norm), _ptr(q_norm), int(k),

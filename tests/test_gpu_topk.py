@@ -36,17 +36,32 @@ def run_topk(dev, Q, Y, k, liked=None, y_norm=None, q_norm=None, workspace=True,
     return ids.cpu().numpy(), sc.cpu().numpy()
 
 
+def block_lists(indptr, indices, pos, nrows):
+    """The filter as mirec_topk_order_build lays it out, by host arithmetic: per block of 32 rows the positions
+    any of its rows holds, ascending, each with the set of those rows; the list of block b starts at pair
+    indptr[32 b]."""
+    blocks = np.zeros((max(indices.size, 1), 2), dtype=np.int32)
+    lens = np.zeros(max((nrows + 31) // 32, 1), dtype=np.int32)
+    for b in range((nrows + 31) // 32):
+        sets = {}
+        for r in range(32 * b, min(32 * b + 32, nrows)):
+            for i in indices[indptr[r]:indptr[r + 1]]:
+                sets[int(pos[i])] = sets.get(int(pos[i]), 0) | (1 << (r - 32 * b))
+        base = int(indptr[32 * b])
+        for j, p in enumerate(sorted(sets)):
+            blocks[base + j] = (p, np.uint32(sets[p]).astype(np.int32))
+        lens[b] = len(sets)
+    return blocks, lens
+
+
 def given_order(dev, liked, perm):
-    """(item_order, positions) on the device for a permutation chosen by the test: host arithmetic."""
+    """(item_order, blocks, block_len) on the device for a permutation chosen by the test."""
     import torch
     perm = np.asarray(perm, dtype=np.int32)
     pos = np.empty_like(perm)
     pos[perm] = np.arange(perm.size, dtype=np.int32)
-    positions = pos[liked.indices]
-    for r in range(liked.shape[0]):
-        a, b = liked.indptr[r], liked.indptr[r + 1]
-        positions[a:b] = np.sort(positions[a:b])
-    return (torch.from_numpy(perm).to(dev), torch.from_numpy(np.ascontiguousarray(positions, dtype=np.int32)).to(dev))
+    blocks, lens = block_lists(liked.indptr, liked.indices, pos, liked.shape[0])
+    return (torch.from_numpy(perm).to(dev), torch.from_numpy(blocks).to(dev), torch.from_numpy(lens).to(dev))
 
 
 @pytest.mark.parametrize("nq,ni,f,k", [
@@ -135,14 +150,17 @@ def test_topk_plane_kernel_near_ties_and_hand_over(dev):
 
 
 def test_sweep_order_build_matches_host_arithmetic(dev):
-    """mirec_topk_order_build: items by (interactions descending, index ascending), every filter row renumbered to
-    positions and ascending; rows of every length against a wavefront (0, 1, 63, 64, 65, 700, all items), items
-    nobody has, and an item named twice in a row."""
+    """mirec_topk_order_build: items by (interactions descending, index ascending); the filter as one list per
+    32 rows of (position, row set), ascending.  Row counts that are not a multiple of 32, empty rows and
+    blocks, rows that hold every item, items nobody has, a catalogue longer than one pass of the list kernel
+    (32 768 positions), and an item named twice in a row."""
     import torch
     from movie_recommender_system_amd import engine as E
     rng = np.random.default_rng(5)
-    for ni, lens in ((1, [1, 0, 1]), (70, [0, 1, 63, 64, 65, 70, 3]), (3000, [0, 700, 64, 3000, 1, 129, 5, 0]),
-                     (27001, list(rng.integers(0, 200, size=300)) + [27001, 0, 2048])):
+    cases = [(1, [1, 0, 1]), (70, [0, 1, 63, 64, 65, 70, 3]), (3000, [0, 700, 64, 3000, 1, 129, 5, 0] + [0] * 40 + [17]),
+             (27001, list(rng.integers(0, 200, size=300)) + [27001, 0, 2048]),
+             (70000, list(rng.integers(0, 90, size=100)) + [40000])]
+    for ni, lens in cases:
         rows = [np.sort(rng.choice(ni, size=n, replace=False)).astype(np.int32) for n in lens]
         indptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
         indices = np.concatenate(rows).astype(np.int32)
@@ -152,19 +170,22 @@ def test_sweep_order_build_matches_host_arithmetic(dev):
         torch.cuda.synchronize()
         count = np.bincount(indices, minlength=ni)
         want_order = np.lexsort((np.arange(ni), -count)).astype(np.int32)
-        got_order, got_pos = m.order[0].cpu().numpy(), m.order[1].cpu().numpy()[:indices.size]
-        assert np.array_equal(got_order, want_order)
+        assert np.array_equal(m.order[0].cpu().numpy(), want_order)
         pos = np.empty(ni, dtype=np.int32)
         pos[want_order] = np.arange(ni, dtype=np.int32)
-        for r, row in enumerate(rows):
-            assert np.array_equal(got_pos[indptr[r]:indptr[r + 1]], np.sort(pos[row])), (ni, r)
-    # an item twice in one row: one position, the tail repeats the row's last position
+        want_blocks, want_len = block_lists(indptr, indices, pos, len(lens))
+        got_blocks, got_len = m.order[1].cpu().numpy(), m.order[2].cpu().numpy()
+        assert np.array_equal(got_len, want_len)
+        for b in range(want_len.size):
+            a = int(indptr[32 * b])
+            assert np.array_equal(got_blocks[a:a + want_len[b]], want_blocks[a:a + want_len[b]]), (ni, b)
+    # an item twice in one row: one pair
     indptr = np.array([0, 4], dtype=np.int64)
     indices = np.array([2, 2, 5, 7], dtype=np.int32)
     m = E.DeviceCSR(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev), torch.ones(4, device=dev), (1, 9))
     assert m.build_order()
-    order, got = m.order[0].cpu().numpy(), m.order[1].cpu().numpy()
-    assert list(order[:3]) == [2, 5, 7] and list(got) == [0, 1, 2, 2]
+    assert list(m.order[0].cpu().numpy()[:3]) == [2, 5, 7] and int(m.order[2][0]) == 3
+    assert m.order[1].cpu().numpy()[:3].tolist() == [[0, 1], [1, 1], [2, 1]]
 
 
 @pytest.mark.parametrize("nq,ni,f,k", [
@@ -200,10 +221,33 @@ def test_topk_in_a_sweep_order_gives_the_same_bits(dev, nq, ni, f, k):
     wsb = int(lib.mirec_topk_workspace_bytes(nq, ni, W, k))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
     perm = torch.from_numpy(np.ascontiguousarray(by_norm, dtype=np.int32)).to(dev)
-    E._lib.check(lib.mirec_topk_ordered(dQ.data_ptr(), nq, dY.data_ptr(), ni, W, None, None, perm.data_ptr(), None, k,
-                                        out_i.data_ptr(), out_s.data_ptr(), ws.data_ptr(), wsb, None), "ordered")
+    E._lib.check(lib.mirec_topk_ordered(dQ.data_ptr(), nq, dY.data_ptr(), ni, W, None, None, perm.data_ptr(), None, None,
+                                        k, out_i.data_ptr(), out_s.data_ptr(), ws.data_ptr(), wsb, None), "ordered")
     torch.cuda.synchronize()
     assert np.array_equal(out_i.cpu().numpy(), pid) and np.array_equal(out_s.cpu().numpy(), psc)
+
+
+def test_topk_ordered_row_views(dev):
+    """Scoring rows [a, b) of a matrix whose order was built on the whole: a view that starts at a block of 32 rows
+    keeps the order (the lists are addressed from the view's first row), any other start falls back to the plain
+    sweep; both give the oracle's bits."""
+    import torch
+    from movie_recommender_system_amd import engine as E
+    rng = np.random.default_rng(21)
+    nu, ni, f, k = 700, 3000, 64, 20
+    X = rng.standard_normal((nu, f)).astype(np.float32)
+    Y = (rng.standard_normal((ni, f)) * rng.gamma(2.0, 1.0, size=(ni, 1))).astype(np.float32)
+    liked = sp.random(nu, ni, density=0.02, random_state=np.random.RandomState(3), format="csr", dtype=np.float32)
+    liked.sort_indices()
+    oid, osc = oracle.topk(X, Y, k, liked=liked)
+    dX, dY = E.pad_factors(X, f, dev), E.pad_factors(Y, f, dev)
+    m = E.DeviceCSR.from_scipy(liked, dev)
+    assert m.build_order()
+    for a, b in ((0, 700), (64, 700), (320, 333), (96, 128), (33, 500), (1, 2)):
+        v = m.rows(a, b)
+        assert (v.order is not None) == (a % 32 == 0)
+        ids, sc = E.topk(dX[a:b], dY, k, v, path="sweep")
+        assert np.array_equal(ids.cpu().numpy(), oid[a:b]) and np.array_equal(sc.cpu().numpy(), osc[a:b]), (a, b)
 
 
 def test_topk_in_a_sweep_order_ties_short_lists_and_hand_over(dev):

@@ -59,13 +59,3 @@ print("order build (once per matrix): %.2f ms" % a.elapsed_time(b), flush=True)
 ids1, sc1 = timed(Y, mask, "by descending interactions")
 print("same bits:", bool((ids1 == ids0).all()) and bool((sc1 == sc0).all()), flush=True)
 
-# any permutation may be handed in: by descending norm of the trained factors
-order = torch.argsort(norms, descending=True, stable=True)          # position -> item
-pos = torch.empty_like(order)
-pos[order] = torch.arange(I, device=dev)                            # item -> position
-rows = torch.repeat_interleave(torch.arange(U, device=dev), indptr[1:] - indptr[:-1])
-key, _ = torch.sort(rows * I + pos[indices.long()])
-mask2 = E.DeviceCSR(indptr, indices, data, (U, I))
-mask2.order = (order.to(torch.int32), (key % I).to(torch.int32))
-ids2, sc2 = timed(Y, mask2, "by descending norm")
-print("same bits:", bool((ids2 == ids0).all()) and bool((sc2 == sc0).all()), flush=True)

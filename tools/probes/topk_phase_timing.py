@@ -1,4 +1,5 @@
-"""Phase timing of the bf16-plane top-K kernel (library built with -DMIREC_DEBUG_TIMING for topk_inst_3.hip).
+"""Phase timing of the bf16-plane top-K kernel: needs a library whose F = 128 unit was built with the cycle-counter
+patch (tools/probes/patches) and exports mirec_topk_debug_read.
 
 usage: topk_phase_timing.py <libmirec variant> [ALS iterations]
 Prints, per tile and per wavefront, the mean cycle counts of the sections of the sweep: with random factors, or --
@@ -38,9 +39,7 @@ ordered = E.DeviceCSR(indptr, indices, data, (U, I))
 ordered.build_order()
 lib = _lib.require()
 out = (ctypes.c_ulonglong * 16)()
-NAMES = ["scores out of the accumulators", "wait: next image staged", "liked-item walk",
-         "selection + next tile's matrix instructions", "compactions + second offers", "wait: old image read",
-         "staging"]
+ntile = (I + 31) // 32
 for mask in (Cui, ordered, None):
     E.topk(X, Y, 20, mask)
     torch.cuda.synchronize()
@@ -52,7 +51,12 @@ for mask in (Cui, ordered, None):
     torch.cuda.synchronize()
     lib.mirec_topk_debug_read(out, 1)
     v = list(out)
-    nt = max(v[8], 1)
-    print("filter=%s ordered=%s %.2f ms; per tile:" % (mask is not None, mask is ordered, e0.elapsed_time(e1)),
-          "; ".join("%s %.0f" % (n, v[i] / nt) for i, n in enumerate(NAMES)),
-          "; total %.0f; final stage %.0f cycles per workgroup" % (sum(v[:7]) / nt, v[7] / max(nt / ((I + 31) // 32), 1)))
+    nt = max(v[5], 1)           # wavefront-tiles
+    nw = nt / ntile             # wavefronts
+    print("filter=%s ordered=%s %.2f ms" % (mask is not None, mask is ordered, e0.elapsed_time(e1)))
+    print("  per wavefront: prologue %.0f, sweep %.0f, final stage %.0f cycles" % (v[7] / nw, v[0] / nw, v[6] / nw))
+    print("  per tile: wait for flags %.0f; staging issue + operands + products %.0f; wait for own pieces %.0f; "
+          "flags + largest sum %.0f; walk %.0f; second stage and compactions %.0f"
+          % (v[1] / nt, v[10] / nt, v[9] / nt, v[11] / nt, v[8] / nt, v[2] / nt))
+    print("  tiles that took the second stage %.1f %%, tiles with a liked item %.1f %%" % (100.0 * v[3] / nt, 100.0 * v[4] / nt),
+          flush=True)
