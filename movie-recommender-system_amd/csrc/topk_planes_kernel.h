@@ -54,6 +54,8 @@
 // Builds that leave out one part each (wrong results, timing only; tools/probes/patches): without the matrix
 // instructions 13.7 ms, without selection and walk 17.4 ms.
 #pragma once
+#include <type_traits>
+
 #include "topk_kernel.h"
 #include "topk_workspace.h"
 
@@ -203,6 +205,10 @@ __device__ __forceinline__ void tk_wait_all(const int* p, int need, int lane) {
     while (__ballot(lane < NW && tk_load_acquire(p + (lane < NW ? lane : 0)) < need) != 0ull) __builtin_amdgcn_s_sleep(1);
 }
 
+#ifndef MIREC_TOPK_AHEAD
+#define MIREC_TOPK_AHEAD 3
+#endif
+
 template <int F, int NW, int CAP, int PD>
 struct TopkPlanesLds {
     static constexpr int NQ = 32 * NW;  // queries of a workgroup
@@ -321,8 +327,12 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     constexpr int BI = TOPK_BI;
     constexpr int NQ = L::NQ;
     constexpr int RING = L::RING;
-    constexpr int D = PD - 2;  // images requested ahead of the tile being multiplied
-    static_assert(D >= 2 && L::NPW <= 3, "staging depth");
+    // Images requested ahead of the tile whose operands are being read.  The rest of the ring, PD - D - 1 slots, is
+    // how many tiles the wavefronts of a workgroup may drift apart before the leaders wait for a slot.
+    constexpr int D = MIREC_TOPK_AHEAD;
+    // (at least two: a wavefront's own newest request is announced as landed only an iteration later, and it waits for
+    // the image of the next tile)
+    static_assert(D >= 2 && D <= PD - 2 && L::NPW <= 3, "staging depth");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ybuf = reinterpret_cast<char*>(smem);
@@ -518,19 +528,20 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
             }
         }
     }
-    // Liked bits of the tile [i0, i0 + 32) for this lane's query, or -- want == false -- only the step past them.
-    auto walk_blocks = [&](int i0, bool want) __attribute__((always_inline)) -> unsigned {
+    // Liked bits of the tile [i0, i0 + 32) for this lane's query.  Entries in front of the tile belong to tiles that
+    // were not worked: they are passed over.
+    auto walk_blocks = [&](int i0) __attribute__((always_inline)) -> unsigned {
         const int lim = i0 + BI;
         bool any = false;
         for (;;) {
             const int nlt = __builtin_popcountll(__ballot(bpos0 < lim));  // the list is sorted: a prefix
             if (nlt > cons) {
-                if (want) {
+                if (__ballot(lane >= cons && lane < nlt && bpos0 >= i0) != 0ull) {
                     if (!any) {
                         if (lane < 32) mwl[lane] = 0u;
                         __builtin_amdgcn_wave_barrier();
                     }
-                    if (lane >= cons && lane < nlt) {
+                    if (lane >= cons && lane < nlt && bpos0 >= i0) {
                         const unsigned bit = 1u << (bpos0 - i0);
                         unsigned rm = brm0;
                         while (rm != 0u) {
@@ -576,16 +587,25 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         soff[j] = sval[j] ? row * F8 + ch : 0;
         npw += piece < L::NPIECE ? 1 : 0;
     }
-    auto dma = [&](int t) __attribute__((always_inline)) {
+    // (Issued as an assembly statement: a load that the compiler knows to write LDS makes it wait for all loads in
+    // flight in front of every later LDS access, the flag reads of the next tile included, which would leave no
+    // image on its way while another is multiplied.  What orders the readers behind these loads is the wait on
+    // the load counter before `staged` is advanced.)
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ybuf;
+    auto dma = [&](int tv) __attribute__((always_inline)) {
+        const int t = __builtin_amdgcn_readfirstlane(tv);  // the same in all lanes: base address and slot are scalars
         const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G;
-        char* slot = ybuf + (t % PD) * L::IMGB;
+        const unsigned slot = lds_base + (unsigned)((t % PD) * L::IMGB);
 #pragma unroll
         for (int j = 0; j < L::NPW; ++j) {
             const int piece = w + NW * j;
             if (piece < L::NPIECE && sval[j]) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + soff[j]),
-                    (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(soff[j] * 16), "s"(src), "s"(slot + (unsigned)(piece * 1024))
+                    : "memory");
             }
         }
     };
@@ -613,134 +633,207 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         }
     };
 
-    // A operands: item c of the tile, hi plane
-    tk_u32x4 ya[KS];
-    auto fetch = [&](int t) __attribute__((always_inline)) {
-        const char* yb = ybuf + (t % PD) * L::IMGB + c * L::ROWB + 16 * h;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) ya[s] = *reinterpret_cast<const tk_u32x4*>(yb + 32 * s);
-    };
     // lane l < 8 looks at the images landed of wavefront l, lane 8 + l at the images read of wavefront l
     const int* my_word = sync + (lane < 16 ? lane : 0);
     const int need_off = lane < 8 ? 1 : D - PD + 1;
 
-    // One tile.  The sweep multiplies the hi planes only (a third of the products) and looks at the largest of a
-    // lane's sixteen sums: what the two products with a mid plane can add is bounded by cmarg times the tile's
-    // largest row norm, so where sum + bound stays at or below the entry threshold for every query of the
-    // wavefront, no score of the tile can enter a buffer and the tile is done.  Otherwise the other two
-    // products follow (the mid plane of the tile comes straight from the workspace, which the cache holds: the
-    // image in LDS is the hi plane) and the scores go through the selection.
-    for (int t = 0; t < ntile; ++t) {
-        const int i0 = t * BI;
-        // the image of tile t is complete, and the slot of tile t + D is free: everybody has the operands of
-        // the tile that was there in registers
-        {
-            const int need = t + need_off;
+    // The sweep multiplies the hi planes only (a third of the products) and looks at the largest of a lane's
+    // sixteen sums: what the two products with a mid plane can add is bounded by cmarg times the tile's largest
+    // row norm, so where sum + bound stays at or below the entry threshold for every query of the wavefront, no
+    // score of the tile can enter a buffer, now or later (thresholds only rise), and the tile is done.  A tile that
+    // fails the test is only marked.  The marked tiles of a stretch of the sweep are worked off when the stretch
+    // ends: each wavefront takes both planes of its marked tiles straight from the workspace (which the cache
+    // holds), forms all three products and runs the selection.  While tiles are swept, every wavefront does the
+    // same short step and the ring of images keeps them together; while marked tiles are worked off, no wavefront
+    // needs another -- a wavefront with many of them holds the rest up only at the end of the stretch, instead
+    // of at every one of its tiles.  Stretches double from one tile to SEG tiles (the thresholds move fastest
+    // at the start) and stay there.
+    constexpr int SEG = 64;
+    unsigned marks = 0u;  // lane l: tiles 32 l .. 32 l + 31 of the stretch (SEG <= 2048)
+    int dma_next = D < ntile ? D : ntile;  // the images of the tiles below this number have been requested
+    // Wait until the image of tile t is complete and the slot that the next request overwrites is free: everybody
+    // has the operands of the tile that was there in registers.  `seen`: this lane's progress word as read earlier.
+    auto ready = [&](int t, int seen) __attribute__((always_inline)) {
+        const int need = t + need_off;
+        if (__ballot(lane < 16 && (lane & 7) < NW && seen < need) != 0ull) {
             while (__ballot(lane < 16 && (lane & 7) < NW && tk_load_acquire(my_word) < need) != 0ull)
                 __builtin_amdgcn_s_sleep(1);
         }
-        if (t + D < ntile) dma(t + D);
-        fetch(t);
+    };
+    // the sixteen sums of a lane against the entry threshold: true = the tile has to be worked
+    auto test = [&](const f32x16& a, float tn) __attribute__((always_inline)) -> bool {
+        float best = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
+        best = fmaxf(best, fmaxf(fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]))));
+        return __ballot(fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr) != 0ull;
+    };
+    auto mark = [&](int rel) __attribute__((always_inline)) { marks |= lane == (rel >> 5) ? 1u << (rel & 31) : 0u; };
+    // One stretch [a, b) of the sweep, software-pipelined by hand: between the eight products of tile t the
+    // wavefront issues the operand reads of tile t + 1, the reads of its progress word and of the next tile norm,
+    // and the test of tile t - 1 -- a matrix instruction keeps the pipe for 32 cycles and the issue port for
+    // 8, so what fits into the gaps is free, and nothing in the loop waits for a latency it has just started.
+    // (The operand of k-step s is read into the registers that the product of that k-step has just taken its
+    // operand from: one set of operand registers, each read a whole tile ahead of its use.)
+    tk_u32x4 ya[KS];
+    f32x16 acc[2];
+    float tnv = 0.f;  // lane l: the largest row norm of tile l of the stretch (a scalar load in the loop would make
+                      // every wait for an operand a wait for everything in flight)
+    static_assert(SEG <= 64, "one tile norm per lane");
+    auto tnorm = [&](int rel) __attribute__((always_inline)) -> float {
+        return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tnv), rel));
+    };
+    auto fetch_part = [&](int t, int s0, int s1) __attribute__((always_inline)) {
+        const char* yb = ybuf + (t % PD) * L::IMGB + c * L::ROWB + 16 * h;
+#pragma unroll
+        for (int s = s0; s < s1; ++s) ya[s] = *reinterpret_cast<const tk_u32x4*>(yb + 32 * s);
+    };
+    auto pipelined_tile = [&](int t, int a, int b, int& seen, auto set) __attribute__((always_inline)) {
+        constexpr int P = decltype(set)::value;
+        const bool next = t + 1 < b;
+        bool issued = false;
+        if (next) {
+            ready(t + 1, seen);
+            if (dma_next < ntile) {
+                dma(dma_next++);
+                issued = true;
+            }
+        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bool work_prev = false;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            acc[P] = tk_mma(ya[s], qh[s], s == 0 ? zero : acc[P]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (next) fetch_part(t + 1, s, s + 1);
+            if (s == (KS > 4 ? 4 : KS - 1) && t > a) work_prev = test(acc[P ^ 1], tnorm(t - 1 - a));
+            if (s == (KS > 5 ? 5 : KS - 1)) seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (work_prev) mark(t - 1 - a);
+        // this wavefront's pieces of the images requested before this tile's have landed, and its operands of
+        // tile t are in registers
+        if (npw > 0) tk_wait_vm(issued ? npw : 0);
+        asm volatile("" ::: "memory");
+        if (lane == 0) {
+            __hip_atomic_store(staged + w, issued ? dma_next - 1 : dma_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(read_done + w, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto sweep_stretch = [&](int a, int b) __attribute__((always_inline)) {
+        int seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ready(a, seen);
+        if (dma_next < ntile && dma_next <= a + D) dma(dma_next++);
+        fetch_part(a, 0, KS);
+        tnv = tile_norm[a + lane < ntile ? a + lane : ntile - 1];
+        for (int t = a; t < b; t += 2) {
+            pipelined_tile(t, a, b, seen, std::integral_constant<int, 0>{});
+            if (t + 1 < b) pipelined_tile(t + 1, a, b, seen, std::integral_constant<int, 1>{});
+        }
+        // the last tile of the stretch
+        const int last = b - 1;
+        const bool odd = ((last - a) & 1) != 0;
+        if (odd ? test(acc[1], tnorm(last - a)) : test(acc[0], tnorm(last - a))) mark(last - a);
+    };
+    auto work_tile = [&](int t) __attribute__((always_inline)) {
+        const int i0 = t * BI;
+        // item c of the tile, both planes, factors 16 s + 8 h .. + 7
+        const tk_u32x4* tp = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G + c * F8 + h;
+        tk_u32x4 yh[KS], ym[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) yh[s] = tp[2 * s];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ym[s] = tp[BI * F8 + 2 * s];
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 acc = zero;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = tk_mma(ya[s], qh[s], acc);
-        // this wavefront's pieces of the image of tile t + D - 1 have landed (those of tile t + D may be on their
-        // way), and its operands of tile t are in registers
-        if (npw > 0) tk_wait_vm(t + D < ntile ? npw : 0);
-        asm volatile("" ::: "memory");
-        if (lane == 0) {
-            const int landed = t + D < ntile ? t + D : ntile;
-            __hip_atomic_store(staged + w, landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(read_done + w, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int s = 0; s < KS; ++s) acc = tk_mma(yh[s], qh[s], acc);  // hi hi
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = tk_mma(yh[s], qm[s], acc);  // hi mid
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = tk_mma(ym[s], qh[s], acc);  // mid hi
+        // mid * mid is below 2^-16 of |q| |y| and left to the margin
+        float sc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = acc[i];
+        if (t == ntile - 1) {  // rows past the last item
+            const int left = (int)(ni - i0) - 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = tk_rowpos(i) < left ? sc[i] : -INFINITY;
         }
-
-        float best = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])), fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
-        best = fmaxf(best, fmaxf(fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])),
-                                 fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]))));
-        const float tn = tile_norm[t];
-        const bool look = fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr;
-
-        const bool second = __ballot(look) != 0ull;
-        // liked items of the tile: per query in the walker lanes, or (BLOCKS) in both lanes of a query's pair
-        unsigned mw = 0u;
+        // liked bits of this lane's 16 items: bit tk_rowpos(i)
+        unsigned liked = 0u;
         if constexpr (BLOCKS) {
             // the first entry not yet passed sits in lane `cons`
-            if (__builtin_amdgcn_readlane(bpos0, cons) < i0 + BI) mw = walk_blocks(i0, second);
+            if (__builtin_amdgcn_readlane(bpos0, cons) < i0 + BI) liked = walk_blocks(i0) >> (4 * h);
         } else {
+            unsigned mw = 0u;
             if (__ballot(nxt < i0 + BI || (nxt == 0x7fffffff && cur < mlen)) != 0ull) {
                 mask_refill_commit();
                 mw = walk_tile(i0);
                 mask_refill_issue();
             }
+            if (mask_indptr != nullptr) liked = (unsigned)__builtin_amdgcn_ds_bpermute(c << 2, (int)mw) >> (4 * h);
         }
-
-        if (second) {
-            tk_u32x4 ym[KS];
-            const tk_u32x4* mp = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G + BI * F8 + c * F8 + h;
+        unsigned fail = 0u;
+        // candidates are few: a group of four scores is looked at only where its best beats the threshold
 #pragma unroll
-            for (int s = 0; s < KS; ++s) ym[s] = mp[2 * s];
+        for (int g = 0; g < 4; ++g) {
+            const float best4 = fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3]));
+            if (best4 > thr) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc = tk_mma(ya[s], qm[s], acc);  // hi mid
-#pragma unroll
-            for (int s = 0; s < KS; ++s) acc = tk_mma(ym[s], qh[s], acc);  // mid hi
-            // mid * mid is below 2^-16 of |q| |y| and left to the margin
-            float sc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[i] = acc[i];
-            if (t == ntile - 1) {  // rows past the last item
-                const int left = (int)(ni - i0) - 4 * h;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sc[i] = tk_rowpos(i) < left ? sc[i] : -INFINITY;
-            }
-            // liked bits of this lane's 16 items: bit tk_rowpos(i)
-            unsigned liked = 0u;
-            if constexpr (BLOCKS)
-                liked = mw >> (4 * h);
-            else if (mask_indptr != nullptr)
-                liked = (unsigned)__builtin_amdgcn_ds_bpermute(c << 2, (int)mw) >> (4 * h);
-            unsigned fail = 0u;
-            // candidates are few: a group of four scores is looked at only where its best beats the threshold
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float best4 = fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3]));
-                if (best4 > thr) {
-#pragma unroll
-                    for (int i = 4 * g; i < 4 * g + 4; ++i) {
-                        if (sc[i] > thr && !((liked >> tk_rowpos(i)) & 1u)) {
-                            if (!append(sc[i], i0 + tk_rowpos(i) + 4 * h)) fail |= 1u << i;
-                        }
-                    }
-                }
-            }
-            // Buffers that were full: compact (every query of the wavefront, which raises all thresholds) and
-            // offer the candidates that were turned away again.  A second compaction covers a tile whose
-            // candidates alone overfill the space a compaction leaves; after that the query is given up.
-            int offers = 0;
-            while (__ballot(fail != 0u) != 0ull) {
-                if (offers == 2) {
-                    if (fail != 0u) {
-                        ovf = true;
-                        thr = INFINITY;
-                    }
-                    break;
-                }
-                ++offers;
-                compact();
-                const unsigned again = fail;
-                fail = 0u;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (((again >> i) & 1u) && sc[i] > thr) {
+                for (int i = 4 * g; i < 4 * g + 4; ++i) {
+                    if (sc[i] > thr && !((liked >> tk_rowpos(i)) & 1u)) {
                         if (!append(sc[i], i0 + tk_rowpos(i) + 4 * h)) fail |= 1u << i;
                     }
                 }
             }
         }
-        // Thresholds only rise at a compaction.  While they are far from their final values (the first tiles
-        // of a sweep) every wavefront compacts on a schedule the whole workgroup shares: the powers of two -- the
-        // fill of a buffer grows with the logarithm of the tile number.
-        if (t >= 2 && (t & (t - 1)) == 0) compact();
+        // Buffers that were full: compact (every query of the wavefront, which raises all thresholds) and offer
+        // the candidates that were turned away again.  A second compaction covers a tile whose candidates alone
+        // overfill the space a compaction leaves; after that the query is given up.
+        int offers = 0;
+        while (__ballot(fail != 0u) != 0ull) {
+            if (offers == 2) {
+                if (fail != 0u) {
+                    ovf = true;
+                    thr = INFINITY;
+                }
+                break;
+            }
+            ++offers;
+            compact();
+            const unsigned again = fail;
+            fail = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (((again >> i) & 1u) && sc[i] > thr) {
+                    if (!append(sc[i], i0 + tk_rowpos(i) + 4 * h)) fail |= 1u << i;
+                }
+            }
+        }
+    };
+    for (int seg_a = 0; seg_a < ntile;) {
+        int seg_b = seg_a == 0 ? 1 : (seg_a < SEG ? 2 * seg_a : seg_a + SEG);
+        seg_b = seg_b < ntile ? seg_b : ntile;
+        sweep_stretch(seg_a, seg_b);
+        // the marked tiles in ascending order (the filter is walked forward only)
+        unsigned long long lanes_marked = __ballot(marks != 0u);
+        if (lanes_marked != 0ull) {
+            while (lanes_marked != 0ull) {
+                const int l = __builtin_ctzll(lanes_marked);
+                lanes_marked &= lanes_marked - 1ull;
+                unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)marks, l);
+                while (bits != 0u) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    work_tile(seg_a + 32 * l + b);
+                }
+            }
+            marks = 0u;
+            // thresholds only rise at a compaction: what the stretch has added is counted in before the next
+            compact();
+        }
+        seg_a = seg_b;
     }
 
     // ---- margin set -> exact scores -> the k best, for the 32 queries of the wavefront

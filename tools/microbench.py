@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--short-max", type=int, default=-1)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--trained", type=int, default=0, help="topk: factors from this many ALS iterations, not random")
+    ap.add_argument("--order", action="store_true", help="topk: sweep the items by descending interactions")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     U, I, f = a.users, a.items, a.factors
@@ -57,7 +59,18 @@ def main():
         W = E.factor_width(f, True)
         X = torch.randn((U, W), device=dev, generator=g) * 0.3
         Y = torch.randn((I, W), device=dev, generator=g) * 0.3
-        mask = None if a.no_mask else Cui
+        if a.trained:
+            import numpy as np
+            rs = np.random.RandomState(42)
+            X = E.pad_factors(rs.rand(U, f).astype(np.float32) * 0.01, W, dev)
+            Y = E.pad_factors(rs.rand(I, f).astype(np.float32) * 0.01, W, dev)
+            eng = E.AlsEngine(Cui, None, X, Y, 0.01, 3)
+            for _ in range(a.trained):
+                eng.iteration()
+            torch.cuda.synchronize()
+        mask = None if a.no_mask else E.DeviceCSR(indptr, indices, data, (U, I))
+        if a.order and mask is not None:
+            mask.build_order()
         mn, av = timeit(lambda: E.topk(X, Y, a.k, mask), a.reps)
         fl = 2.0 * U * I * W
         print(f"topk U={U} I={I} f={W} k={a.k} mask={not a.no_mask}: min {mn:.2f} ms avg {av:.2f} ms  "

@@ -51,12 +51,9 @@ for mask in (Cui, ordered, None):
     torch.cuda.synchronize()
     lib.mirec_topk_debug_read(out, 1)
     v = list(out)
-    nt = max(v[5], 1)           # wavefront-tiles
-    nw = nt / ntile             # wavefronts
+    nw = max(v[6], 1)           # wavefronts
     print("filter=%s ordered=%s %.2f ms" % (mask is not None, mask is ordered, e0.elapsed_time(e1)))
-    print("  per wavefront: prologue %.0f, sweep %.0f, final stage %.0f cycles" % (v[7] / nw, v[0] / nw, v[6] / nw))
-    print("  per tile: wait for flags %.0f; staging issue + operands + products %.0f; wait for own pieces %.0f; "
-          "flags + largest sum %.0f; walk %.0f; second stage and compactions %.0f"
-          % (v[1] / nt, v[10] / nt, v[9] / nt, v[11] / nt, v[8] / nt, v[2] / nt))
-    print("  tiles that took the second stage %.1f %%, tiles with a liked item %.1f %%" % (100.0 * v[3] / nt, 100.0 * v[4] / nt),
+    print("  cycles per wavefront: prologue %.0f, tiles swept %.0f (%.0f per tile), marked tiles worked %.0f "
+          "(%.1f tiles, %.0f each), compactions at stretch ends %.0f, final stage %.0f"
+          % (v[0] / nw, v[1] / nw, v[1] / nw / ntile, v[2] / nw, v[5] / nw, v[2] / max(v[5], 1), v[3] / nw, v[4] / nw),
           flush=True)
