@@ -341,8 +341,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     int* cnt = reinterpret_cast<int*>(smem + L::CNT);
     int* rings = reinterpret_cast<int*>(smem + L::RINGS);
     int* sync = reinterpret_cast<int*>(smem + L::SYNC);
-    int* staged = sync;         // [w]: the shares of wavefront w of the images of the tiles below this number are in LDS
-    int* read_done = sync + 8;  // [w]: wavefront w has its operands of the tiles below this number in registers
+    // progress of wavefront w, one 8-byte store: sync[2 w] = its shares of the images of the tiles below this number
+    // are in LDS; sync[2 w + 1] = it has its operands of the tiles below this number in registers
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -592,27 +592,38 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // image on its way while another is multiplied.  What orders the readers behind these loads is the wait on
     // the load counter before `staged` is advanced.)
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ybuf;
+    auto dma_piece = [&](const tk_u32x4* src, unsigned dst, int voff) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(src), "s"(dst)
+                     : "memory");
+    };
+    int voff[L::NPW];
+#pragma unroll
+    for (int j = 0; j < L::NPW; ++j) voff[j] = soff[j] * 16;
+    // the slot of the next request, as a byte offset that wraps around the ring
+    int dma_slot = 0;
     auto dma = [&](int tv) __attribute__((always_inline)) {
         const int t = __builtin_amdgcn_readfirstlane(tv);  // the same in all lanes: base address and slot are scalars
         const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G;
-        const unsigned slot = lds_base + (unsigned)((t % PD) * L::IMGB);
+        const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)dma_slot));
+        dma_slot = dma_slot + L::IMGB == PD * L::IMGB ? 0 : dma_slot + L::IMGB;
 #pragma unroll
         for (int j = 0; j < L::NPW; ++j) {
             const int piece = w + NW * j;
-            if (piece < L::NPIECE && sval[j]) {
-                unsigned keep;
-                asm volatile(
-                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                    : "=&s"(keep)
-                    : "v"(soff[j] * 16), "s"(src), "s"(slot + (unsigned)(piece * 1024))
-                    : "memory");
+            // a piece that ends inside the image needs no lane mask
+            if ((j + 1) * NW * 1024 <= L::IMGB) {
+                dma_piece(src, slot + (unsigned)(piece * 1024), voff[j]);
+            } else if (piece < L::NPIECE) {
+                if (sval[j]) dma_piece(src, slot + (unsigned)(piece * 1024), voff[j]);
             }
         }
     };
     for (int t = 0; t < D; ++t)
         if (t < ntile) dma(t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid < L::SYNC_WORDS) sync[tid] = tid < 8 ? (D < ntile ? D : ntile) : 0;
+    if (tid < L::SYNC_WORDS) sync[tid] = (tid & 1) == 0 ? (D < ntile ? D : ntile) : 0;
     __syncthreads();  // tiles 0 to D - 1 are staged, the progress words and fill counts are set
 
     // One candidate: reserve a slot of the query's buffer and fill it; false: the buffer is full.
@@ -633,9 +644,10 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         }
     };
 
-    // lane l < 8 looks at the images landed of wavefront l, lane 8 + l at the images read of wavefront l
+    // lane 2 l looks at the images landed of wavefront l, lane 2 l + 1 at the images read of wavefront l
     const int* my_word = sync + (lane < 16 ? lane : 0);
-    const int need_off = lane < 8 ? 1 : D - PD + 1;
+    const int need_off = (lane & 1) == 0 ? 1 : D - PD + 1;
+    const bool watcher = lane < 2 * NW;
 
     // The sweep multiplies the hi planes only (a third of the products) and looks at the largest of a lane's
     // sixteen sums: what the two products with a mid plane can add is bounded by cmarg times the tile's largest
@@ -655,9 +667,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // has the operands of the tile that was there in registers.  `seen`: this lane's progress word as read earlier.
     auto ready = [&](int t, int seen) __attribute__((always_inline)) {
         const int need = t + need_off;
-        if (__ballot(lane < 16 && (lane & 7) < NW && seen < need) != 0ull) {
-            while (__ballot(lane < 16 && (lane & 7) < NW && tk_load_acquire(my_word) < need) != 0ull)
-                __builtin_amdgcn_s_sleep(1);
+        if (__ballot(watcher && seen < need) != 0ull) {
+            while (__ballot(watcher && tk_load_acquire(my_word) < need) != 0ull) __builtin_amdgcn_s_sleep(1);
         }
     };
     // the sixteen sums of a lane against the entry threshold: true = the tile has to be worked
@@ -666,11 +677,27 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         best = fmaxf(best, fmaxf(fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]))));
         return __ballot(fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr) != 0ull;
     };
+    // the same in eight instructions (a maximum written in the language costs an extra instruction per input,
+    // which quiets signalling NaNs; v_max3_f32 returns the other operands where one is a NaN, as fmaxf does).
+    // Only where the sums are old: the assembler statement hides from the compiler that they come from the
+    // matrix pipe, whose results must not be read too early.
+    auto test_fast = [&](const f32x16& a, float tn) __attribute__((always_inline)) -> bool {
+        auto max3 = [](float x, float y, float z) __attribute__((always_inline)) -> float {
+            float r;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+            return r;
+        };
+        const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
+        const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
+        const float best = max3(max3(m0, m1, m2), max3(m3, m4, a[15]), -INFINITY);
+        return __ballot(fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr) != 0ull;
+    };
     auto mark = [&](int rel) __attribute__((always_inline)) { marks |= lane == (rel >> 5) ? 1u << (rel & 31) : 0u; };
     // One stretch [a, b) of the sweep, software-pipelined by hand: between the eight products of tile t the
-    // wavefront issues the operand reads of tile t + 1, the reads of its progress word and of the next tile norm,
-    // and the test of tile t - 1 -- a matrix instruction keeps the pipe for 32 cycles and the issue port for
-    // 8, so what fits into the gaps is free, and nothing in the loop waits for a latency it has just started.
+    // wavefront issues the operand reads of tile t + 1, the read of its progress word, and the test of tile
+    // t - 1 -- a matrix instruction keeps the pipe for 32 cycles and the issue port for 8, so what fits into the
+    // gaps is free, and nothing in the loop waits for a latency it has just started.  The loop is bound by the
+    // number of instructions beside the products, so there are no branches in a tile but the rare ones out of it.
     // (The operand of k-step s is read into the registers that the product of that k-step has just taken its
     // operand from: one set of operand registers, each read a whole tile ahead of its use.)
     tk_u32x4 ya[KS];
@@ -681,16 +708,23 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     auto tnorm = [&](int rel) __attribute__((always_inline)) -> float {
         return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tnv), rel));
     };
-    auto fetch_part = [&](int t, int s0, int s1) __attribute__((always_inline)) {
-        const char* yb = ybuf + (t % PD) * L::IMGB + c * L::ROWB + 16 * h;
+    const char* ylane = ybuf + c * L::ROWB + 16 * h;  // this lane's row and half in slot 0
+    int fetch_slot = 0;                               // the slot of the tile whose operands are read next
+    auto fetch_part = [&](int s0, int s1) __attribute__((always_inline)) {
+        const char* yb = ylane + fetch_slot;
 #pragma unroll
         for (int s = s0; s < s1; ++s) ya[s] = *reinterpret_cast<const tk_u32x4*>(yb + 32 * s);
     };
-    auto pipelined_tile = [&](int t, int a, int b, int& seen, auto set) __attribute__((always_inline)) {
-        constexpr int P = decltype(set)::value;
-        const bool next = t + 1 < b;
+    auto fetch_advance = [&]() __attribute__((always_inline)) {
+        fetch_slot = fetch_slot + L::IMGB == PD * L::IMGB ? 0 : fetch_slot + L::IMGB;
+    };
+    long long* my_progress = reinterpret_cast<long long*>(sync + 2 * w);
+    // parity P: which accumulator takes tile t; NEXT: tile t + 1 belongs to the stretch
+    auto pipelined_tile = [&](int t, int a, int& seen, auto parity, auto has_next) __attribute__((always_inline)) {
+        constexpr int P = decltype(parity)::value;
+        constexpr bool NEXT = decltype(has_next)::value;
         bool issued = false;
-        if (next) {
+        if constexpr (NEXT) {
             ready(t + 1, seen);
             if (dma_next < ntile) {
                 dma(dma_next++);
@@ -704,35 +738,48 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         for (int s = 0; s < KS; ++s) {
             acc[P] = tk_mma(ya[s], qh[s], s == 0 ? zero : acc[P]);
             __builtin_amdgcn_sched_barrier(0);
-            if (next) fetch_part(t + 1, s, s + 1);
-            if (s == (KS > 4 ? 4 : KS - 1) && t > a) work_prev = test(acc[P ^ 1], tnorm(t - 1 - a));
+            if constexpr (NEXT) fetch_part(s, s + 1);
+            if (s == (KS > 4 ? 4 : KS - 1) && t > a) work_prev = test_fast(acc[P ^ 1], tnorm(t - 1 - a));
             if (s == (KS > 5 ? 5 : KS - 1)) seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (NEXT) fetch_advance();
         if (work_prev) mark(t - 1 - a);
         // this wavefront's pieces of the images requested before this tile's have landed, and its operands of
         // tile t are in registers
         if (npw > 0) tk_wait_vm(issued ? npw : 0);
         asm volatile("" ::: "memory");
         if (lane == 0) {
-            __hip_atomic_store(staged + w, issued ? dma_next - 1 : dma_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(read_done + w, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const long long v = (long long)(unsigned)(issued ? dma_next - 1 : dma_next) | ((long long)(t + 1) << 32);
+            __hip_atomic_store(my_progress, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
+    using T = std::true_type;
+    using N = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
     auto sweep_stretch = [&](int a, int b) __attribute__((always_inline)) {
         int seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ready(a, seen);
         if (dma_next < ntile && dma_next <= a + D) dma(dma_next++);
-        fetch_part(a, 0, KS);
+        fetch_part(0, KS);
+        fetch_advance();
         tnv = tile_norm[a + lane < ntile ? a + lane : ntile - 1];
-        for (int t = a; t < b; t += 2) {
-            pipelined_tile(t, a, b, seen, std::integral_constant<int, 0>{});
-            if (t + 1 < b) pipelined_tile(t + 1, a, b, seen, std::integral_constant<int, 1>{});
+        int t = a;
+        for (; t + 2 < b; t += 2) {
+            pipelined_tile(t, a, seen, P0{}, T{});
+            pipelined_tile(t + 1, a, seen, P1{}, T{});
         }
-        // the last tile of the stretch
-        const int last = b - 1;
-        const bool odd = ((last - a) & 1) != 0;
-        if (odd ? test(acc[1], tnorm(last - a)) : test(acc[0], tnorm(last - a))) mark(last - a);
+        bool work_last;
+        if (t + 1 < b) {
+            pipelined_tile(t, a, seen, P0{}, T{});
+            pipelined_tile(t + 1, a, seen, P1{}, N{});
+            work_last = test(acc[1], tnorm(b - 1 - a));
+        } else {
+            pipelined_tile(t, a, seen, P0{}, N{});
+            work_last = test(acc[0], tnorm(b - 1 - a));
+        }
+        if (work_last) mark(b - 1 - a);
     };
     auto work_tile = [&](int t) __attribute__((always_inline)) {
         const int i0 = t * BI;
