@@ -167,6 +167,52 @@ __global__ __launch_bounds__(32 * (F / 8)) void topk_split_items_kernel(const fl
     }
 }
 
+// A sweep order made inside the call, for a call that brings none and has no filter (whose rows an order would
+// have to be renumbered to): the items by descending row norm, as exactly as 4096 bins of the norm's leading bits
+// tell -- which is all the sweep needs, since any order gives the same results and a nearly sorted one nearly
+// all of the saving.  Three small launches: count per bin, offsets (one workgroup), place.  Items of one bin land in
+// the order the atomics decide; the results of the call do not depend on it.
+__device__ __forceinline__ int tk_norm_bin(const float* __restrict__ y, int f) {
+    float s = 0.f;
+    for (int j = 0; j < f; ++j) s = fmaf(y[j], y[j], s);
+    // a norm is not negative: its bits order like the value; a NaN has the largest
+    return (TOPK_ORDER_BINS - 1) - (int)(__float_as_uint(fabsf(s)) >> 19);  // descending: bin 0 = largest
+}
+template <int F>
+__global__ __launch_bounds__(256) void topk_order_count_kernel(const float* __restrict__ Y, int64_t ni, int32_t* bins) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < ni) atomicAdd(bins + tk_norm_bin(Y + i * F, F), 1);
+}
+template <int F>
+__global__ __launch_bounds__(1024) void topk_order_scan_kernel(int32_t* bins) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    int v[TOPK_ORDER_BINS / 1024], sum = 0;
+    for (int j = 0; j < TOPK_ORDER_BINS / 1024; ++j) {
+        v[j] = bins[t * (TOPK_ORDER_BINS / 1024) + j];
+        sum += v[j];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int at = part[t] - sum;
+    for (int j = 0; j < TOPK_ORDER_BINS / 1024; ++j) {
+        bins[t * (TOPK_ORDER_BINS / 1024) + j] = at;
+        at += v[j];
+    }
+}
+template <int F>
+__global__ __launch_bounds__(256) void topk_order_place_kernel(const float* __restrict__ Y, int64_t ni, int32_t* bins,
+                                                               int32_t* __restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < ni) order[atomicAdd(bins + tk_norm_bin(Y + i * F, F), 1)] = (int32_t)i;
+}
+
 // Register i of a lane in half h of a 32 x 32 MFMA result is row tk_rowpos(i) + 4 * h.
 __device__ __forceinline__ constexpr int tk_rowpos(int i) { return (i & 3) + 8 * (i >> 2); }
 
@@ -997,6 +1043,17 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
     const int ntile = (int)((ni + TOPK_BI - 1) / TOPK_BI);
 
     MIREC_HIP(hipMemsetAsync(base, 0, 256, stream));
+    if (item_order == nullptr && mask_indptr == nullptr) {
+        int32_t* bins = reinterpret_cast<int32_t*>(base + lay.bins_off);
+        int32_t* made = reinterpret_cast<int32_t*>(base + lay.order_off);
+        MIREC_HIP(hipMemsetAsync(bins, 0, TOPK_ORDER_BINS * 4, stream));
+        const unsigned nb = (unsigned)((ni + 255) / 256);
+        hipLaunchKernelGGL((topk_order_count_kernel<F>), dim3(nb), dim3(256), 0, stream, Y, ni, bins);
+        hipLaunchKernelGGL((topk_order_scan_kernel<F>), dim3(1), dim3(1024), 0, stream, bins);
+        hipLaunchKernelGGL((topk_order_place_kernel<F>), dim3(nb), dim3(256), 0, stream, Y, ni, bins, made);
+        MIREC_LAUNCH_CHECK();
+        item_order = made;
+    }
     hipLaunchKernelGGL((topk_split_items_kernel<F>), dim3((unsigned)ntile), dim3(32 * (F / 8)), 0, stream, Y, ni,
                        item_order, planes, tile_norm, ymax_bits);
     MIREC_LAUNCH_CHECK();

@@ -3,6 +3,8 @@
 //   [0, 256)            header: u32 bits of max ||y|| at byte 0, i32 length of the query list at byte 4
 //   [256, 256 + Lq)     query list: int32 per query (Lq = 4*nq rounded up to 256)
 //   [.., .. + Ln)       largest row norm of every item tile: float per tile (Ln rounded up to 256)
+//   [.., .. + Lo)       a sweep order made inside the call (no filter, no order given): 4096 bin counters, then
+//                       int32 per item
 //   [.., .. + Lp)       item factors split into two bf16 planes (hi, mid), tile by tile:
 //                       [tile][plane][32 items][f] bf16, rows past the last item zero
 #pragma once
@@ -13,13 +15,14 @@ namespace mirec {
 
 constexpr int TOPK_PLANE_KMAX = 24;  // largest k the bf16-plane kernel serves
 constexpr int TOPK_NPLANES = 2;      // bf16 planes per factor matrix
+constexpr int TOPK_ORDER_BINS = 4096;  // bins of the in-call sweep order: the top 12 bits of a row norm
 
 inline bool topk_planes_supported(int f, int k) {
     return f >= 16 && f <= 128 && f % 16 == 0 && k >= 1 && k <= TOPK_PLANE_KMAX;
 }
 
 struct TopkWorkspace {
-    size_t qlist_off, tnorm_off, planes_off, bytes;
+    size_t qlist_off, tnorm_off, bins_off, order_off, planes_off, bytes;
 };
 
 inline TopkWorkspace topk_workspace_layout(int64_t nq, int64_t ni, int f) {
@@ -28,7 +31,9 @@ inline TopkWorkspace topk_workspace_layout(int64_t nq, int64_t ni, int f) {
     const size_t lq = ((size_t)nq * 4 + 255) / 256 * 256;
     const size_t ntile = (size_t)((ni + 31) / 32);
     w.tnorm_off = w.qlist_off + lq;
-    w.planes_off = w.tnorm_off + (ntile * 4 + 255) / 256 * 256;
+    w.bins_off = w.tnorm_off + (ntile * 4 + 255) / 256 * 256;
+    w.order_off = w.bins_off + TOPK_ORDER_BINS * 4;
+    w.planes_off = w.order_off + ((size_t)ni * 4 + 255) / 256 * 256;
     w.bytes = w.planes_off + ntile * TOPK_NPLANES * 32 * (size_t)f * 2;
     return w;
 }

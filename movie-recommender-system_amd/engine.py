@@ -410,6 +410,7 @@ class AlsEngine:
 
 # Up to this many queries the items are split over the workgroups (mirec_topk_small); beyond it the queries
 # are (mirec_topk).  Measured crossover at 27 k items, f = 128, k = 20 (tools/probes/topk_small_crossover.py).
+ORDER_MIN_QUERIES = 32768     # from this many queries on, a filter without a sweep order gets one made
 SMALL_TOPK_QUERIES = 2048
 SMALL_TOPK_WS_LIMIT = 512 << 20   # ... unless the tiles' partial lists would need more than this
 
@@ -471,6 +472,8 @@ def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = N
         ws_bytes = int(lib.mirec_topk_workspace_bytes(nq, ni, f, int(k)))
         if ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Q.device)
+    if ws is not None and mask is not None and mask.order is None and nq >= ORDER_MIN_QUERIES and mask.shape[1] == ni:
+        mask.build_order()    # worth its cost within this one pass; a matrix that is kept keeps the order too
     if ws is not None and mask is not None and mask.order is not None and mask.shape[1] == ni:
         item_order, blocks, block_len = mask.order
         _lib.check(lib.mirec_topk_ordered(_ptr(Q), nq, _ptr(Y), ni, f, _ptr(mask.indptr), _ptr(mask.indices),

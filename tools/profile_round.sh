@@ -16,7 +16,7 @@ for side in user item; do
   done
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/topk_$c -o p -- python3 $R/tools/microbench.py topk --reps 2 > $O/topk_$c.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/topk_$c -o p -- python3 $R/tools/microbench.py topk --reps 2 --trained 6 --order > $O/topk_$c.log 2>&1
 done
 cd $R
 python3 tools/pmc_summary.py $O/pmc_traffic.json $O/user_FETCH_SIZE $O/user_WRITE_SIZE $O/item_FETCH_SIZE $O/item_WRITE_SIZE $O/topk_FETCH_SIZE $O/topk_WRITE_SIZE
