@@ -588,13 +588,15 @@ def main():
         useful = 2.0 * nu_l * I * (nc + 2)
         extra["lightfm_roofline"] = {
             "users": nu_l, "items": I, "no_components": nc, "scoring_width": Wl,
-            "topk_kernel": "topk_planes_kernel<%d, 8, 48, 3>" % Wl, "topk_kernel_ms": t_top,
+            "topk_kernel": "topk_planes_kernel<%d, 8, 48, 6, true>" % Wl, "topk_kernel_ms": t_top,
             "users_per_s_kernel_only": nu_l / ((t_top + t_seg) * 1e-3),
             "users_per_s_incl_transfers": nu_l / tl,
-            "bound": "mfma", "achieved": useful / (t_top * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
-            "frac": useful / (t_top * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 3.0),
+            "bound": "mfma", "achieved": useful / (t_top * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": useful / (t_top * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "note": "achieved = 2*users*items*(nc+2) useful flops / kernel time (the operand rows are padded to "
-                    "scoring_width columns); peak = dense bf16 peak / 3 plane products",
+                    "scoring_width columns); peak = dense bf16 peak, one plane product per multiply-add (earlier "
+                    "rounds: a third of it); the sweep at this width is bound by the instructions beside its two "
+                    "matrix instructions per tile, not by the matrix pipe",
             "segment_sum": {"kernel": "lightfm_repr_kernel", "ms": t_seg, "bound": "hbm", "bytes": seg_bytes,
                             "achieved": seg_bytes / (t_seg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": seg_bytes / (t_seg * 1e-3) / 1e9 / HBM_PEAK_GBS}}
