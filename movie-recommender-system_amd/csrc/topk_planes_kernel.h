@@ -945,12 +945,19 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         cnt[q] = answer ? nfin : -1;
     }
     // exact score of every survivor: the fp32 chain s = fma(q[k], y[k], s), ascending k, from +0.  The lane in
-    // half h takes the entries 2j + h of its query, whose row it keeps in registers.
+    // half h takes the entries 2j + h of its query, whose row it keeps in registers.  The item rows are read by
+    // four lanes each: a lane that fetched its own 512-byte row 16 bytes at a time would touch 64 cache lines per
+    // load instruction of the wavefront, and the lookups, not the bytes, set the pace.  The four lanes of a quad
+    // take their four rows in turn -- each lane loads a quarter of every 64-byte piece of the row on turn -- and run
+    // the chain with the row's values passed around the quad by the instruction's own lane select; the lane whose
+    // row it is keeps the sum (the other three multiply their own query with a row that is not theirs, for nothing).
     {
         f32x4 qv[F / 4];
         const float* qr = Q + (uv ? ug : 0) * F;
 #pragma unroll
         for (int k4 = 0; k4 < F / 4; ++k4) qv[k4] = *reinterpret_cast<const f32x4*>(qr + 4 * k4);
+        constexpr int NSEG = F / 16;  // 64-byte pieces of a row
+        const int r4 = lane & 3;
         for (int j = 0;; ++j) {
             const int e = 2 * j + h;
             const bool act = e < nfin;
@@ -961,31 +968,63 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
                 id = id < 0 ? 0 : (id < ni ? id : (int)ni - 1);
                 if (act) sel_i[e * NQ + q] = id;
             }
-            const float* yr = Y + (int64_t)id * F;
-            float s = 0.f;
-            // the row in groups of G 16-byte loads, the next group in flight during the chain of the current one
-            constexpr int G = (F / 4) % 8 == 0 ? 8 : 4;
-            f32x4 yv[2][G];
+            float mine = 0.f;
+            // the four rows of the quad, by turn
+            const int id0 = __builtin_amdgcn_mov_dpp(id, 0x00, 0xf, 0xf, true);
+            const int id1 = __builtin_amdgcn_mov_dpp(id, 0x55, 0xf, 0xf, true);
+            const int id2 = __builtin_amdgcn_mov_dpp(id, 0xaa, 0xf, 0xf, true);
+            const int id3 = __builtin_amdgcn_mov_dpp(id, 0xff, 0xf, 0xf, true);
+            f32x4 ya[NSEG], yb[NSEG];
+            auto load_row = [&](int item, f32x4 (&yv)[NSEG]) __attribute__((always_inline)) {
+                const float* yr = Y + (int64_t)item * F + 4 * r4;
 #pragma unroll
-            for (int g = 0; g < G; ++g) yv[0][g] = *reinterpret_cast<const f32x4*>(yr + 4 * g);
+                for (int g = 0; g < NSEG; ++g) yv[g] = *reinterpret_cast<const f32x4*>(yr + 16 * g);
+            };
+            // s = fma(q, y of lane `src` of the quad, s): the multiply-add takes its first factor through the quad
+            // permutation, so passing the row around costs no instruction of its own
+            auto chain = [&](const f32x4 (&yv)[NSEG]) __attribute__((always_inline)) -> float {
+                float s = 0.f;
 #pragma unroll
-            for (int k0 = 0; k0 < F / 4; k0 += G) {
-                const int b = (k0 / G) & 1;
-                if (k0 + G < F / 4) {
+                for (int g = 0; g < NSEG; ++g) {
+                    // elements 16 g .. 16 g + 15: four from each lane of the quad, in lane order
 #pragma unroll
-                    for (int g = 0; g < G; ++g) yv[b ^ 1][g] = *reinterpret_cast<const f32x4*>(yr + 4 * (k0 + G + g));
+                    for (int x = 0; x < 4; ++x)
+                        asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
+                            : "+v"(s) : "v"(yv[g][x]), "v"(qv[4 * g][x]));
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
+                            : "+v"(s) : "v"(yv[g][x]), "v"(qv[4 * g + 1][x]));
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+                            : "+v"(s) : "v"(yv[g][x]), "v"(qv[4 * g + 2][x]));
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+                            : "+v"(s) : "v"(yv[g][x]), "v"(qv[4 * g + 3][x]));
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    s = __builtin_fmaf(qv[k0 + g][0], yv[b][g][0], s);
-                    s = __builtin_fmaf(qv[k0 + g][1], yv[b][g][1], s);
-                    s = __builtin_fmaf(qv[k0 + g][2], yv[b][g][2], s);
-                    s = __builtin_fmaf(qv[k0 + g][3], yv[b][g][3], s);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (act) sel_s[e * NQ + q] = s;
+                return s;
+            };
+            load_row(id0, ya);
+            load_row(id1, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            float s = chain(ya);
+            mine = r4 == 0 ? s : mine;
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(id2, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            s = chain(yb);
+            mine = r4 == 1 ? s : mine;
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(id3, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            s = chain(ya);
+            mine = r4 == 2 ? s : mine;
+            __builtin_amdgcn_sched_barrier(0);
+            s = chain(yb);
+            mine = r4 == 3 ? s : mine;
+            if (act) sel_s[e * NQ + q] = mine;
         }
     }
     __builtin_amdgcn_wave_barrier();
