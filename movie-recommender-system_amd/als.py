@@ -441,10 +441,11 @@ class AlternatingLeastSquares:
                 return ids.cpu().numpy(), scores.cpu().numpy()
             # many users: chunk by chunk, each chunk's download overlapping the next chunk's kernels
             dl = E.ChunkedDownload(n, int(N), dev)
+            order = E.norm_order(Yd) if dmask is None else None   # without a filter: one sweep order for all chunks
             for a, b in dl.ranges():
                 # (the kernels index the filter's row pointers by query and read absolute offsets: a view will do)
                 m = None if dmask is None else dmask.rows(a, b)
-                ids, scores = E.topk(Q[a:b], Yd, int(N), m, path="sweep")
+                ids, scores = E.topk(Q[a:b], Yd, int(N), m, path="sweep", item_order=order)
                 dl.submit(_hide_filtered(ids, scores, m), scores, a)
             return dl.finish()
 

@@ -443,14 +443,18 @@ def topk_small(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCS
 
 def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = None,
          y_norm: Optional[torch.Tensor] = None, q_norm: Optional[torch.Tensor] = None,
-         n_items: Optional[int] = None, workspace: bool = True, path: str = "auto"):
+         n_items: Optional[int] = None, workspace: bool = True, path: str = "auto",
+         item_order: Optional[torch.Tensor] = None):
     """Fused score + top-k of every row of Q against the first n_items rows of Y.
     Returns device tensors (ids int32 [nq, k], scores fp32 [nq, k]).  With
     ``workspace`` the library's scratch (for the bf16-plane kernel, where it
     applies) is taken from torch's caching allocator; results are identical
     either way.  ``path``: "sweep" = the all-users kernels (queries split over
     the workgroups), "small" = the per-request kernels (items split), "auto" =
-    by the number of queries."""
+    by the number of queries.  ``item_order`` (without a filter): a sweep
+    order for the all-users kernel (``norm_order``), for a caller that scores
+    chunk after chunk against the same items; without it the library makes
+    one inside every call."""
     lib = _lib.require()
     nq, f = Q.shape
     ni = int(Y.shape[0] if n_items is None else n_items)
@@ -480,10 +484,21 @@ def topk(Q: torch.Tensor, Y: torch.Tensor, k: int, mask: Optional[DeviceCSR] = N
                                           _ptr(item_order), _ptr(blocks), _ptr(block_len), int(k), _ptr(ids),
                                           _ptr(scores), _ptr(ws), ws_bytes, _stream_ptr()), "mirec_topk_ordered")
         return ids, scores
+    if ws is not None and mask is None and item_order is not None:
+        assert item_order.dtype == torch.int32 and int(item_order.numel()) == ni
+        _lib.check(lib.mirec_topk_ordered(_ptr(Q), nq, _ptr(Y), ni, f, None, None, _ptr(item_order), None, None, int(k),
+                                          _ptr(ids), _ptr(scores), _ptr(ws), ws_bytes, _stream_ptr()), "mirec_topk_ordered")
+        return ids, scores
     _lib.check(lib.mirec_topk(_ptr(Q), nq, _ptr(Y), ni, f, _ptr(None if mask is None else mask.indptr),
                               _ptr(None if mask is None else mask.indices), _ptr(y_norm), _ptr(q_norm), int(k),
                               _ptr(ids), _ptr(scores), _ptr(ws), ws_bytes, _stream_ptr()), "mirec_topk")
     return ids, scores
+
+
+def norm_order(Y: torch.Tensor, n_items: Optional[int] = None) -> torch.Tensor:
+    """The items by descending row norm (int32, position -> item): a sweep order for ``topk`` without a filter."""
+    ni = int(Y.shape[0] if n_items is None else n_items)
+    return torch.argsort(Y[:ni].norm(dim=1), descending=True, stable=True).to(torch.int32)
 
 
 class ChunkedDownload:

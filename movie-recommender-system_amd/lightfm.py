@@ -209,8 +209,9 @@ class LightFMScorer:
                 return ids.cpu().numpy(), scores.cpu().numpy()
             # many users: chunk by chunk, each chunk's download overlapping the next chunk's kernels
             dl = E.ChunkedDownload(n, int(k), dev)
+            order = E.norm_order(Y)       # one sweep order for all chunks
             for a, b in dl.ranges():
-                ids, scores = E.topk(Q[a:b], Y, int(k), path="sweep")
+                ids, scores = E.topk(Q[a:b], Y, int(k), path="sweep", item_order=order)
                 dl.submit(ids, scores, a)
             return dl.finish()
 

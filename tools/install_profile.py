@@ -1,10 +1,10 @@
 """Turn one capture of tools/profile_round.sh (gpurun_out/<tag>/) into the committed summaries under profiles/.
 
 usage: python tools/install_profile.py <tag> <previous tag> "<one-line description of the capture>"
-Writes profiles/<tag>_bench_kernel_stats.{md,csv}, _bench_line.json, _pmc_traffic.json; carries the notes below
-the table over from the previous tag, removes the previous tag's files (but for the L2 and SQ counter files,
-which keep the tag of their own capture) and renames the references to them in the design notes at the
-repository root.
+Writes profiles/<tag>_bench_kernel_stats.{md,csv}, _bench_line.json, _pmc_traffic.json, with the traffic table made
+from the counter file.  A previous tag of the SAME round (same rNN prefix) is replaced: its files are removed (but
+for the L2 and SQ counter files, which keep the tag of their own capture) and the references to them in the design
+notes at the repository root renamed; an earlier round's files stay.
 """
 import csv
 import glob
@@ -36,21 +36,36 @@ out += (f"\nbench.py's live HIP-event figures without the profiler (`{tag}_bench
         f"included); WARP epoch {e['lightfm_warp_examples_per_s_incl_transfers'] / 1e6:.1f} M examples/s including its transfers"
         + (f" ({e['lightfm_warp_first_epoch_examples_per_s_incl_transfers'] / 1e6:.1f} M/s for a fresh model's first epoch)"
            if "lightfm_warp_first_epoch_examples_per_s_incl_transfers" in e else "")
-        + ".  (The boxes of this pool differ by a few per cent:\ncapture h, with identical ALS kernels, ran 14.30 ms per iteration "
-          "and 34.39 ms per top-20 pass; the L2 counter file is that capture's.)\n\n")
-out += old[old.index("Traffic beyond L2 per launch"):].replace(prev + "_", tag + "_")
+        + f"; the sweep order of the top-20 pass built in {e.get('top20_order_build_ms', float('nan')):.1f} ms, once per matrix."
+          "  (The boxes of this pool differ by up to a tenth in kernel time.)\n\n")
+t = json.load(open(os.path.join(src, "pmc_traffic.json")))
+gb = lambda side, kern: next((v["hbm_bytes_per_launch"] / 1e9 for n, v in t.get(side, {}).items() if kern in n), float("nan"))
+rl = {r["side"] + ":" + r["kernel"].split("<")[0]: r for r in e.get("half_sweep_rooflines", [])}
+alg = lambda key: rl[key]["bytes_per_launch"] / 1e9 if key in rl else float("nan")
+out += (f"Traffic beyond L2 per launch (`{tag}_pmc_traffic.json`; TCC FETCH_SIZE and WRITE_SIZE, one counter per pass, in units of\n"
+        "1 KiB with the read counter doubled as the gfx950 correction prescribes):\n\n"
+        "| kernel | beyond-L2 GB per launch | algorithmic GB per launch |\n|---|---|---|\n"
+        f"| als_short_mfma_kernel (user half-sweep) | {gb('user', 'als_short_mfma_kernel'):.2f} | {alg('user:als_short_mfma_kernel'):.2f} |\n"
+        f"| als_gram_cg_kernel (item half-sweep) | {gb('item', 'als_gram_cg_kernel'):.2f} | {alg('item:als_gram_cg_kernel'):.2f} |\n"
+        f"| topk_planes_kernel (all-users top-20, items by descending interactions, trained factors) | {gb('topk', 'topk_planes_kernel'):.2f} | "
+        "0.93 (queries, item planes once, liked items, results) |\n\n"
+        "The user half-sweep's gathered table (27 000 x 128 fp32 = 13.8 MB) exceeds the 4 MiB L2 of an XCD and is served by the\n"
+        "Infinity Cache: its traffic beyond L2 is gather re-reads, not HBM traffic.  The top-K sweep reads the hi plane of the items\n"
+        "(6.9 MB) once per workgroup of 256 queries through L2; what goes beyond L2 is the queries, the results, the filter lists and\n"
+        "the part of the final stage's item-row gathers that misses.\n")
 open(os.path.join(prof, f"{tag}_bench_kernel_stats.md"), "w").write(out)
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
 open(os.path.join(prof, f"{tag}_bench_line.json"), "w").write(json.dumps(d) + "\n")
 shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(prof, f"{tag}_pmc_traffic.json"))
 # counter files that no capture of this script renews stay under the tag of the capture they were taken with
 keep = ("_l2_hit_rates.json", "_sq_counters.json")
-for f in glob.glob(os.path.join(prof, f"{prev}_*")):
-    if not f.endswith(keep):
-        os.remove(f)
-p = os.path.join(root, "DESIGN.md")
-text = open(p).read()   # (read before the file is opened for writing)
-for k in keep:
-    text = text.replace(prev + k, "\0KEEP" + k)
-open(p, "w").write(text.replace(prev + "_", tag + "_").replace("\0KEEP", prev))
+if prev[:3] == tag[:3] and prev != tag:
+    for f in glob.glob(os.path.join(prof, f"{prev}_*")):
+        if not f.endswith(keep):
+            os.remove(f)
+    p = os.path.join(root, "DESIGN.md")
+    text = open(p).read()   # (read before the file is opened for writing)
+    for k in keep:
+        text = text.replace(prev + k, "\0KEEP" + k)
+    open(p, "w").write(text.replace(prev + "_", tag + "_").replace("\0KEEP", prev))
 print(out[:1800])
