@@ -811,6 +811,9 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         fetch_part(0, KS);
         fetch_advance();
         tnv = tile_norm[a + lane < ntile ? a + lane : ntile - 1];
+        // used here once, so that the wait for this load stands here and not in front of its first use inside the
+        // loop, where it would be a wait for every image on its way, tile after tile
+        asm volatile("" : "+v"(tnv));
         int t = a;
         for (; t + 2 < b; t += 2) {
             pipelined_tile(t, a, seen, P0{}, T{});
