@@ -254,6 +254,9 @@ __device__ __forceinline__ void tk_wait_all(const int* p, int need, int lane) {
 #ifndef MIREC_TOPK_AHEAD
 #define MIREC_TOPK_AHEAD 3
 #endif
+#ifndef MIREC_TOPK_STRETCH
+#define MIREC_TOPK_STRETCH 64
+#endif
 
 template <int F, int NW, int CAP, int PD>
 struct TopkPlanesLds {
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // needs another -- a wavefront with many of them holds the rest up only at the end of the stretch, instead
     // of at every one of its tiles.  Stretches double from one tile to SEG tiles (the thresholds move fastest
     // at the start) and stay there.
-    constexpr int SEG = 64;
+    constexpr int SEG = MIREC_TOPK_STRETCH;
     unsigned marks = 0u;  // lane l: tiles 32 l .. 32 l + 31 of the stretch (SEG <= 2048)
     int dma_next = D < ntile ? D : ntile;  // the images of the tiles below this number have been requested
     // Wait until the image of tile t is complete and the slot that the next request overwrites is free: everybody
@@ -748,11 +751,19 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // operand from: one set of operand registers, each read a whole tile ahead of its use.)
     tk_u32x4 ya[KS];
     f32x16 acc[2];
-    float tnv = 0.f;  // lane l: the largest row norm of tile l of the stretch (a scalar load in the loop would make
-                      // every wait for an operand a wait for everything in flight)
-    static_assert(SEG <= 64, "one tile norm per lane");
+    // lane l of register j: the largest row norm of tile 64 j + l of the stretch (a scalar load in the loop would
+    // make every wait for an operand a wait for everything in flight)
+    constexpr int NTN = (SEG + 63) / 64;
+    float tnv[NTN];
+    static_assert(SEG <= 2048, "a mark per tile of the stretch in one register");
     auto tnorm = [&](int rel) __attribute__((always_inline)) -> float {
-        return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tnv), rel));
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const float v = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tnv[j]), rel & 63));
+            r = (rel >> 6) == j ? v : r;
+        }
+        return r;
     };
     const char* ylane = ybuf + c * L::ROWB + 16 * h;  // this lane's row and half in slot 0
     int fetch_slot = 0;                               // the slot of the tile whose operands are read next
@@ -810,10 +821,15 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         if (dma_next < ntile && dma_next <= a + D) dma(dma_next++);
         fetch_part(0, KS);
         fetch_advance();
-        tnv = tile_norm[a + lane < ntile ? a + lane : ntile - 1];
-        // used here once, so that the wait for this load stands here and not in front of its first use inside the
-        // loop, where it would be a wait for every image on its way, tile after tile
-        asm volatile("" : "+v"(tnv));
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const int tj = a + 64 * j + lane;
+            tnv[j] = tile_norm[tj < ntile ? tj : ntile - 1];
+        }
+        // used here once, so that the wait for these loads stands here and not in front of their first use inside
+        // the loop, where it would be a wait for every image on its way, tile after tile
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) asm volatile("" : "+v"(tnv[j]));
         int t = a;
         for (; t + 2 < b; t += 2) {
             pipelined_tile(t, a, seen, P0{}, T{});
