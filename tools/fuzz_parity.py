@@ -95,8 +95,16 @@ def case_topk(rng):
         desc += " norms=" + ("both" if qn is not None else "items")
     oid, osc = oracle.topk(Q, Y, k, liked=liked, y_norm=yn, q_norm=qn)
     ok = True
-    for ws, path in ((True, "sweep"), (False, "sweep"), (True, "small")):
-        ids, sc = E.topk(dQ, dY, k, mask, dyn, dqn, workspace=ws, path=path)
+    # the all-users kernels with and without a workspace (bf16-plane and fp32 kernel), the same with the items in
+    # the sweep order built from the filter, the per-request kernels
+    for ws, path in ((True, "sweep"), (False, "sweep"), (True, "ordered"), (True, "small")):
+        m = mask
+        if path == "ordered":
+            if mask is None or dyn is not None:
+                continue
+            m = E.DeviceCSR(mask.indptr, mask.indices, mask.data, mask.shape)
+            m.build_order()
+        ids, sc = E.topk(dQ, dY, k, m, dyn, dqn, workspace=ws, path="sweep" if path == "ordered" else path)
         ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
         if not (np.array_equal(ids, oid) and np.array_equal(sc, osc)):
             bad = np.nonzero((ids != oid).any(1) | (sc != osc).any(1))[0]
