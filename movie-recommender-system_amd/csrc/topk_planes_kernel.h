@@ -263,11 +263,16 @@ struct TopkPlanesLds {
     static constexpr int NQ = 32 * NW;  // queries of a workgroup
     // The hi plane of an item tile: 32 rows of F bf16, padded by 16 bytes: the row stride in dwords is an odd
     // multiple of four, which puts the 16 rows of every ds_read_b128 group on disjoint banks.  An image is
-    // filled by loads that write LDS directly, 1 KiB (64 lanes x 16 bytes, consecutive) per instruction.
+    // filled by loads that write LDS directly (lanes x 16 bytes, consecutive, per instruction): 2 NW pieces of
+    // 32 / (2 NW) padded rows each, two per wavefront -- the same count for every wavefront, so the wait for its own
+    // pieces is the same instruction everywhere.
     static constexpr int ROWB = 2 * F + 16;
     static constexpr int IMGB = TOPK_BI * ROWB;
-    static constexpr int NPIECE = (IMGB + 1023) / 1024;
-    static constexpr int NPW = (NPIECE + NW - 1) / NW;  // pieces a wavefront issues per tile, at most
+    static constexpr int NPW = 2;                            // pieces a wavefront issues per tile
+    static constexpr int PROWS = TOPK_BI / (NPW * NW);       // image rows per piece
+    static constexpr int PLANES = PROWS * (ROWB / 16);       // lanes of a piece
+    static constexpr int PIECEB = PROWS * ROWB;
+    static_assert(TOPK_BI % (NPW * NW) == 0 && PLANES <= 64, "pieces of whole rows, at most a wavefront wide");
     static constexpr int RING = 8;  // liked-item look-ahead per query (a power of two, at least 8)
     // in floats: the item images; candidate scores and ids, entry-major ([entry][query]: the lanes of a
     // half-wave, one query each, touch 32 consecutive words); fill counts; liked-item rings; the progress words
@@ -349,16 +354,6 @@ __device__ __forceinline__ int tk_compact_all(float* sel_s, int* sel_i, int* cnt
     return total;
 }
 
-// s_waitcnt vmcnt(N) for a wave-uniform N in 0 .. 3 (the instruction takes an immediate).
-__device__ __forceinline__ void tk_wait_vm(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    }
-}
-
 // BLOCKS: the filter comes as one list per 32 queries (a wavefront's), sorted by position of the sweep, each entry
 // a position and the 32-bit set of the block's rows that hold it (mask_indices then points to those pairs and
 // block_len to the lists' lengths; the list of the block that starts at query row r begins at entry
@@ -381,7 +376,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     constexpr int D = MIREC_TOPK_AHEAD;
     // (at least two: a wavefront's own newest request is announced as landed only an iteration later, and it waits for
     // the image of the next tile)
-    static_assert(D >= 2 && D <= PD - 2 && L::NPW <= 3, "staging depth");
+    static_assert(D >= 2 && D <= PD - 2, "staging depth");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ybuf = reinterpret_cast<char*>(smem);
@@ -622,35 +617,30 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // bytes of a piece are consecutive in LDS; each lane computes where its 16 of them come from (a chunk of the
     // row padding repeats the row's last chunk).
     constexpr int TILE_G = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile in the workspace
-    int soff[L::NPW];                               // source chunk of this lane, per piece of this wavefront
-    bool sval[L::NPW];
-    int npw = 0;  // pieces this wavefront issues per tile (wave-uniform)
+    // source of this lane's 16 bytes of a piece, as a byte offset into the tile's hi plane (a chunk of the row
+    // padding repeats the row's last chunk)
+    int voff[L::NPW];
+    const bool plane_lane = lane < L::PLANES;
 #pragma unroll
     for (int j = 0; j < L::NPW; ++j) {
         const int piece = w + NW * j;
-        const int o = piece * 1024 + lane * 16;
-        const int row = o / L::ROWB;
-        int ch = (o % L::ROWB) / 16;
+        const int row = piece * L::PROWS + lane / (F8 + 1);
+        int ch = lane % (F8 + 1);
         ch = ch < F8 ? ch : F8 - 1;
-        sval[j] = o < L::IMGB;
-        soff[j] = sval[j] ? row * F8 + ch : 0;
-        npw += piece < L::NPIECE ? 1 : 0;
+        voff[j] = plane_lane ? (row * F8 + ch) * 16 : 0;
     }
     // (Issued as an assembly statement: a load that the compiler knows to write LDS makes it wait for all loads in
     // flight in front of every later LDS access, the flag reads of the next tile included, which would leave no
     // image on its way while another is multiplied.  What orders the readers behind these loads is the wait on
-    // the load counter before `staged` is advanced.)
+    // the load counter before the progress word is advanced.)
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ybuf;
-    auto dma_piece = [&](const tk_u32x4* src, unsigned dst, int voff) __attribute__((always_inline)) {
+    auto dma_piece = [&](const tk_u32x4* src, unsigned dst, int voffset) __attribute__((always_inline)) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(voff), "s"(src), "s"(dst)
+                     : "v"(voffset), "s"(src), "s"(dst)
                      : "memory");
     };
-    int voff[L::NPW];
-#pragma unroll
-    for (int j = 0; j < L::NPW; ++j) voff[j] = soff[j] * 16;
     // the slot of the next request, as a byte offset that wraps around the ring
     int dma_slot = 0;
     auto dma = [&](int tv) __attribute__((always_inline)) {
@@ -658,15 +648,9 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G;
         const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)dma_slot));
         dma_slot = dma_slot + L::IMGB == PD * L::IMGB ? 0 : dma_slot + L::IMGB;
+        if (plane_lane) {
 #pragma unroll
-        for (int j = 0; j < L::NPW; ++j) {
-            const int piece = w + NW * j;
-            // a piece that ends inside the image needs no lane mask
-            if ((j + 1) * NW * 1024 <= L::IMGB) {
-                dma_piece(src, slot + (unsigned)(piece * 1024), voff[j]);
-            } else if (piece < L::NPIECE) {
-                if (sval[j]) dma_piece(src, slot + (unsigned)(piece * 1024), voff[j]);
-            }
+            for (int j = 0; j < L::NPW; ++j) dma_piece(src, slot + (unsigned)((w + NW * j) * L::PIECEB), voff[j]);
         }
     };
     for (int t = 0; t < D; ++t)
@@ -710,7 +694,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // of at every one of its tiles.  Stretches double from one tile to SEG tiles (the thresholds move fastest
     // at the start) and stay there.
     constexpr int SEG = MIREC_TOPK_STRETCH;
-    unsigned marks = 0u;  // lane l: tiles 32 l .. 32 l + 31 of the stretch (SEG <= 2048)
+    unsigned long long marks = 0ull;  // bit r: tile r of the stretch (the same in all lanes: a pair of scalar registers)
+    static_assert(SEG <= 64, "a mark per tile of the stretch in one 64-bit scalar");
     int dma_next = D < ntile ? D : ntile;  // the images of the tiles below this number have been requested
     // Wait until the image of tile t is complete and the slot that the next request overwrites is free: everybody
     // has the operands of the tile that was there in registers.  `seen`: this lane's progress word as read earlier.
@@ -741,7 +726,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         const float best = max3(max3(m0, m1, m2), max3(m3, m4, a[15]), -INFINITY);
         return __ballot(fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr) != 0ull;
     };
-    auto mark = [&](int rel) __attribute__((always_inline)) { marks |= lane == (rel >> 5) ? 1u << (rel & 31) : 0u; };
+    auto mark = [&](int rel) __attribute__((always_inline)) { marks |= 1ull << rel; };
     // One stretch [a, b) of the sweep, software-pipelined by hand: between the eight products of tile t the
     // wavefront issues the operand reads of tile t + 1, the read of its progress word, and the test of tile
     // t - 1 -- a matrix instruction keeps the pipe for 32 cycles and the issue port for 8, so what fits into the
@@ -755,7 +740,6 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // make every wait for an operand a wait for everything in flight)
     constexpr int NTN = (SEG + 63) / 64;
     float tnv[NTN];
-    static_assert(SEG <= 2048, "a mark per tile of the stretch in one register");
     auto tnorm = [&](int rel) __attribute__((always_inline)) -> float {
         float r = 0.f;
 #pragma unroll
@@ -804,8 +788,9 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         if (work_prev) mark(t - 1 - a);
         // this wavefront's pieces of the images requested before this tile's have landed, and its operands of
         // tile t are in registers
-        if (npw > 0) tk_wait_vm(issued ? npw : 0);
-        asm volatile("" ::: "memory");
+        if (issued) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(L::NPW == 2, "the wait above leaves one tile's pieces of this wavefront in flight");
         if (lane == 0) {
             const long long v = (long long)(unsigned)(issued ? dma_next - 1 : dma_next) | ((long long)(t + 1) << 32);
             __hip_atomic_store(my_progress, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -929,19 +914,12 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         seg_b = seg_b < ntile ? seg_b : ntile;
         sweep_stretch(seg_a, seg_b);
         // the marked tiles in ascending order (the filter is walked forward only)
-        unsigned long long lanes_marked = __ballot(marks != 0u);
-        if (lanes_marked != 0ull) {
-            while (lanes_marked != 0ull) {
-                const int l = __builtin_ctzll(lanes_marked);
-                lanes_marked &= lanes_marked - 1ull;
-                unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)marks, l);
-                while (bits != 0u) {
-                    const int b = __builtin_ctz(bits);
-                    bits &= bits - 1u;
-                    work_tile(seg_a + 32 * l + b);
-                }
+        if (marks != 0ull) {
+            while (marks != 0ull) {
+                const int b = __builtin_ctzll(marks);
+                marks &= marks - 1ull;
+                work_tile(seg_a + b);
             }
-            marks = 0u;
             // thresholds only rise at a compaction: what the stretch has added is counted in before the next
             compact();
         }
