@@ -141,10 +141,12 @@ __global__ __launch_bounds__(32 * (F / 8)) void topk_split_items_kernel(const fl
     }
     tk_u32x4 hi, mid;
     tk_split8(a, b, hi, mid);
-    // [tile][plane][32][F] bf16 = [tile][plane][32][F8] chunks of 16 bytes
-    tk_u32x4* dst = reinterpret_cast<tk_u32x4*>(planes) + (size_t)blockIdx.x * (TOPK_NPLANES * 32 * F8) + j * F8 + kc;
-    dst[0] = hi;
-    dst[32 * F8] = mid;
+    // three sections of 32 F8 chunks of 16 bytes: hi by rows; hi and mid by chunks (chunk kc of all 32 rows, then
+    // chunk kc + 1)
+    tk_u32x4* dst = reinterpret_cast<tk_u32x4*>(planes) + (size_t)blockIdx.x * (TOPK_TILE_SECTIONS * 32 * F8);
+    dst[j * F8 + kc] = hi;
+    dst[32 * F8 + kc * 32 + j] = hi;
+    dst[2 * 32 * F8 + kc * 32 + j] = mid;
     part[tid] = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] +
                 b[3] * b[3];
     __syncthreads();
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // the products; every wavefront issues its share of the pieces of an image (piece p by wavefront p % NW).  The
     // bytes of a piece are consecutive in LDS; each lane computes where its 16 of them come from (a chunk of the
     // row padding repeats the row's last chunk).
-    constexpr int TILE_G = TOPK_NPLANES * BI * F8;  // 16-byte chunks of one tile in the workspace
+    constexpr int TILE_G = TOPK_TILE_SECTIONS * BI * F8;  // 16-byte chunks of one tile in the workspace
     // source of this lane's 16 bytes of a piece, as a byte offset into the tile's hi plane (a chunk of the row
     // padding repeats the row's last chunk)
     int voff[L::NPW];
@@ -831,15 +833,18 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         }
         if (work_last) mark(b - 1 - a);
     };
+    // (The operands of a marked tile come straight from the workspace, from the sections laid out by chunks: the
+    // lanes of a load read 1 KiB in a row.  By rows -- each lane its own row, 32 cache lines per instruction -- the
+    // lookups, not the bytes, made the sixteen loads take as long as everything else that is done for the tile.)
     auto work_tile = [&](int t) __attribute__((always_inline)) {
         const int i0 = t * BI;
-        // item c of the tile, both planes, factors 16 s + 8 h .. + 7
-        const tk_u32x4* tp = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G + c * F8 + h;
+        // item c of the tile, both planes, factors 16 s + 8 h .. + 7: chunk 2 s + h
+        const tk_u32x4* tp = reinterpret_cast<const tk_u32x4*>(planes) + (size_t)t * TILE_G + BI * F8 + h * BI + c;
         tk_u32x4 yh[KS], ym[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) yh[s] = tp[2 * s];
+        for (int s = 0; s < KS; ++s) yh[s] = tp[2 * s * BI];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ym[s] = tp[BI * F8 + 2 * s];
+        for (int s = 0; s < KS; ++s) ym[s] = tp[BI * F8 + 2 * s * BI];
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 acc = zero;
 #pragma unroll

@@ -5,8 +5,11 @@
 //   [.., .. + Ln)       largest row norm of every item tile: float per tile (Ln rounded up to 256)
 //   [.., .. + Lo)       a sweep order made inside the call (no filter, no order given): 4096 bin counters, then
 //                       int32 per item
-//   [.., .. + Lp)       item factors split into two bf16 planes (hi, mid), tile by tile:
-//                       [tile][plane][32 items][f] bf16, rows past the last item zero
+//   [.., .. + Lp)       item factors split into two bf16 planes (hi, mid), tile by tile, three sections a tile,
+//                       rows past the last item zero:
+//                         hi  [32 items][f] bf16                  what the sweep copies into LDS row by row
+//                         hi  [f/8 chunks][32 items][8] bf16      what a lane of a marked tile's products reads: chunk
+//                         mid [f/8 chunks][32 items][8] bf16      2s+h of item c -- a wavefront's load is 1 KiB in a row
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -15,6 +18,7 @@ namespace mirec {
 
 constexpr int TOPK_PLANE_KMAX = 24;  // largest k the bf16-plane kernel serves
 constexpr int TOPK_NPLANES = 2;      // bf16 planes per factor matrix
+constexpr int TOPK_TILE_SECTIONS = 3;  // images of an item tile in the workspace
 constexpr int TOPK_ORDER_BINS = 4096;  // bins of the in-call sweep order: the top 12 bits of a row norm
 
 inline bool topk_planes_supported(int f, int k) {
@@ -34,7 +38,7 @@ inline TopkWorkspace topk_workspace_layout(int64_t nq, int64_t ni, int f) {
     w.bins_off = w.tnorm_off + (ntile * 4 + 255) / 256 * 256;
     w.order_off = w.bins_off + TOPK_ORDER_BINS * 4;
     w.planes_off = w.order_off + ((size_t)ni * 4 + 255) / 256 * 256;
-    w.bytes = w.planes_off + ntile * TOPK_NPLANES * 32 * (size_t)f * 2;
+    w.bytes = w.planes_off + ntile * TOPK_TILE_SECTIONS * 32 * (size_t)f * 2;
     return w;
 }
 

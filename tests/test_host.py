@@ -58,7 +58,7 @@ def test_scoring_width_and_topk_workspace_sizes():
     assert E.scoring_width(17, 100) == 24 and E.scoring_width(128, 100) == 128
     hot = lib.mirec_topk_workspace_bytes
     # header, query list, one norm per item tile, bins and items of an in-call sweep order, the two bf16 planes
-    assert hot(1000, 27000, 128, 20) == 256 + 4096 + 3584 + 4096 * 4 + 108032 + 844 * 2 * 32 * 128 * 2
+    assert hot(1000, 27000, 128, 20) == 256 + 4096 + 3584 + 4096 * 4 + 108032 + 844 * 3 * 32 * 128 * 2
     assert hot(1000, 27000, 128, 25) == 0 and hot(1000, 27000, 160, 20) == 0 and hot(1000, 27000, 24, 20) == 0
     assert hot(0, 27000, 128, 20) == 0 and hot(1000, 0, 128, 20) == 0
 

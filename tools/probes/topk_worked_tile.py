@@ -1,6 +1,12 @@
+"""Where the work on a marked tile of the top-K sweep goes: needs a library whose F = 128 unit was built with the
+worked-tile cycle stamps (tools/probes/build_variant.py <name> topk_inst_3.hip -DMIREC_DEBUG_TIMING_WORKED).
+
+usage: topk_worked_tile.py <libmirec variant>
+The benchmark's factors after six iterations, items by descending interactions.
+"""
 import ctypes, os, sys
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from movie_recommender_system_amd import _lib
 _lib.load(sys.argv[1])
 from movie_recommender_system_amd import engine as E, synth
