@@ -265,16 +265,19 @@ struct TopkPlanesLds {
     static constexpr int NQ = 32 * NW;  // queries of a workgroup
     // The hi plane of an item tile: 32 rows of F bf16, padded by 16 bytes: the row stride in dwords is an odd
     // multiple of four, which puts the 16 rows of every ds_read_b128 group on disjoint banks.  An image is
-    // filled by loads that write LDS directly (lanes x 16 bytes, consecutive, per instruction): 2 NW pieces of
-    // 32 / (2 NW) padded rows each, two per wavefront -- the same count for every wavefront, so the wait for its own
-    // pieces is the same instruction everywhere.
+    // filled by loads that write LDS directly (lanes x 16 bytes, consecutive, per instruction), in pieces of whole
+    // padded rows, as few as fit a wavefront's 64 lanes -- the same number for every sweeping wavefront, so the wait
+    // for its own pieces is the same instruction everywhere.
+    static constexpr int NS = NW / 2;  // wavefronts that sweep: each for its own 32 queries and for those of wavefront + NS
+    static_assert(NW % 2 == 0 && NS >= 1, "sweeping wavefronts pair up with the others");
     static constexpr int ROWB = 2 * F + 16;
     static constexpr int IMGB = TOPK_BI * ROWB;
-    static constexpr int NPW = 2;                            // pieces a wavefront issues per tile
-    static constexpr int PROWS = TOPK_BI / (NPW * NW);       // image rows per piece
+    static constexpr int piece_count(int npw) { return (TOPK_BI / (npw * NS)) * (ROWB / 16) <= 64 ? npw : piece_count(2 * npw); }
+    static constexpr int NPW = piece_count(1);               // pieces a sweeping wavefront issues per tile
+    static constexpr int PROWS = TOPK_BI / (NPW * NS);       // image rows per piece
     static constexpr int PLANES = PROWS * (ROWB / 16);       // lanes of a piece
     static constexpr int PIECEB = PROWS * ROWB;
-    static_assert(TOPK_BI % (NPW * NW) == 0 && PLANES <= 64, "pieces of whole rows, at most a wavefront wide");
+    static_assert(PROWS >= 1 && TOPK_BI % (NPW * NS) == 0 && PLANES <= 64, "pieces of whole rows, at most a wavefront wide");
     static constexpr int RING = 8;  // liked-item look-ahead per query (a power of two, at least 8)
     // in floats: the item images; candidate scores and ids, entry-major ([entry][query]: the lanes of a
     // half-wave, one query each, touch 32 consecutive words); fill counts; liked-item rings; the progress words
@@ -283,9 +286,16 @@ struct TopkPlanesLds {
     static constexpr int CNT = SEL_I + CAP * NQ;
     static constexpr int RINGS = CNT + NQ;
     static constexpr int SYNC = RINGS + NQ * RING;
-    static constexpr int SYNC_WORDS = 32;  // [0, 8): images landed per wavefront; [8, 16): images read
-    static_assert(NW <= 8, "progress words");
-    static constexpr size_t BYTES = (size_t)(SYNC + SYNC_WORDS) * 4;
+    static constexpr int SYNC_WORDS = 32;  // a pair per sweeping wavefront: images landed, images read
+    static_assert(NS <= 8, "progress words");
+    // what a sweeping wavefront needs of its partner's queries (entry thresholds, coarse margins), and what it hands
+    // back (the marks of a stretch, 64 bits per wavefront)
+    static constexpr int XTHR = SYNC + SYNC_WORDS;
+    static constexpr int XCM = XTHR + NQ;
+    static constexpr int XMARK = XCM + NQ;
+    // a byte per tile of a stretch and group, set where a lane's test fails: 64 + 64 per sweeping wavefront
+    static constexpr int XFLAG = XMARK + 2 * NW;
+    static constexpr size_t BYTES = (size_t)(XFLAG + 32 * NS) * 4;
     static constexpr int LIMIT = CAP - 16;  // entries a compaction may leave (at least k)
     static_assert(CAP % 2 == 0 && LIMIT >= TOPK_PLANE_KMAX && LIMIT <= 32, "buffer size");
 };
@@ -373,12 +383,10 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     constexpr int BI = TOPK_BI;
     constexpr int NQ = L::NQ;
     constexpr int RING = L::RING;
-    // Images requested ahead of the tile whose operands are being read.  The rest of the ring, PD - D - 1 slots, is
-    // how many tiles the wavefronts of a workgroup may drift apart before the leaders wait for a slot.
+    // Images a loading wavefront keeps on their way at a time (the ring itself bounds how far the loads run ahead of
+    // the sweep: PD - 1 tiles).
     constexpr int D = MIREC_TOPK_AHEAD;
-    // (at least two: a wavefront's own newest request is announced as landed only an iteration later, and it waits for
-    // the image of the next tile)
-    static_assert(D >= 2 && D <= PD - 2, "staging depth");
+    static_assert(D >= 1 && D <= PD - 1 && D * L::NPW <= 48, "staging depth");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ybuf = reinterpret_cast<char*>(smem);
@@ -387,8 +395,12 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     int* cnt = reinterpret_cast<int*>(smem + L::CNT);
     int* rings = reinterpret_cast<int*>(smem + L::RINGS);
     int* sync = reinterpret_cast<int*>(smem + L::SYNC);
-    // progress of wavefront w, one 8-byte store: sync[2 w] = its shares of the images of the tiles below this number
-    // are in LDS; sync[2 w + 1] = it has its operands of the tiles below this number in registers
+    float* xthr = smem + L::XTHR;
+    float* xcm = smem + L::XCM;
+    unsigned long long* xmark = reinterpret_cast<unsigned long long*>(smem + L::XMARK);
+    unsigned char* xflag = reinterpret_cast<unsigned char*>(smem + L::XFLAG);
+    // sync[l]: the shares of loading wavefront NS + l of the images of the tiles below this number are in LDS;
+    // sync[8 + w]: sweeping wavefront w has its operands of the tiles below this number in registers
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -396,10 +408,14 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const int c = lane & 31;
     const int ntile = (int)((ni + BI - 1) / BI);
     const int q = w * 32 + c;  // this lane pair's query slot
+    constexpr int NS = L::NS;
+    const bool sweeper = w < NS;  // (the same for a whole wavefront)
     const int64_t ug = (int64_t)blockIdx.x * NQ + q;
     const bool uv = ug < nq;
 
     if (h == 0) cnt[q] = 0;
+    if (tid < L::SYNC_WORDS) sync[tid] = 0;
+    __syncthreads();
 
     // B operands: query row ug, factors 16*s + 8*h .. + 7, as two bf16 planes; and the margins of the query
     tk_u32x4 qh[KS], qm[KS];
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const bool plane_lane = lane < L::PLANES;
 #pragma unroll
     for (int j = 0; j < L::NPW; ++j) {
-        const int piece = w + NW * j;
+        const int piece = (sweeper ? 0 : w - NS) + NS * j;
         const int row = piece * L::PROWS + lane / (F8 + 1);
         int ch = lane % (F8 + 1);
         ch = ch < F8 ? ch : F8 - 1;
@@ -652,14 +668,36 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         dma_slot = dma_slot + L::IMGB == PD * L::IMGB ? 0 : dma_slot + L::IMGB;
         if (plane_lane) {
 #pragma unroll
-            for (int j = 0; j < L::NPW; ++j) dma_piece(src, slot + (unsigned)((w + NW * j) * L::PIECEB), voff[j]);
+            for (int j = 0; j < L::NPW; ++j)
+                dma_piece(src, slot + (unsigned)((w - NS + NS * j) * L::PIECEB), voff[j]);
         }
     };
-    for (int t = 0; t < D; ++t)
-        if (t < ntile) dma(t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid < L::SYNC_WORDS) sync[tid] = (tid & 1) == 0 ? (D < ntile ? D : ntile) : 0;
-    __syncthreads();  // tiles 0 to D - 1 are staged, the progress words and fill counts are set
+    // The loading wavefronts' side of the ring: request the images of the tiles below `lim`, each when every sweeping
+    // wavefront has taken its operands of the tile whose slot it overwrites, D tiles on their way at a time.  The
+    // progress word says what has landed (loads complete in order: all but the newest D - 1 requests, after the wait).
+    int dma_next = 0;  // the images of the tiles below this number have been requested
+    const int* done_word = sync + 8 + (lane < NS ? lane : 0);
+    auto load_until = [&](int lim) __attribute__((always_inline)) {
+        int flying = 0;
+        while (dma_next < lim) {
+            const int need = dma_next - PD + 1;  // tiles below this number must have been read
+            if (need > 0) {
+                while (__ballot(lane < NS && tk_load_acquire(done_word) < need) != 0ull) __builtin_amdgcn_s_sleep(1);
+            }
+            dma(dma_next++);
+            if (flying == D - 1) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * L::NPW) : "memory");
+                if (lane == 0) __hip_atomic_store(sync + (w - NS), dma_next - (D - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                ++flying;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(sync + (w - NS), dma_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (!sweeper) load_until(PD - 1 < ntile ? PD - 1 : ntile);
+    if (h == 0) xcm[q] = cmarg;
+    __syncthreads();  // the first tiles are staged, the fill counts and coarse margins are set
 
     // One candidate: reserve a slot of the query's buffer and fill it; false: the buffer is full.
     auto append = [&](float s, int item) __attribute__((always_inline)) -> bool {
@@ -680,44 +718,49 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     };
 
     // lane 2 l looks at the images landed of wavefront l, lane 2 l + 1 at the images read of wavefront l
-    const int* my_word = sync + (lane < 16 ? lane : 0);
-    const int need_off = (lane & 1) == 0 ? 1 : D - PD + 1;
-    const bool watcher = lane < 2 * NW;
+    // lane l of a sweeping wavefront looks at the images landed of loading wavefront l % NS
+    const int* my_word = sync + lane % NS;
 
     // The sweep multiplies the hi planes only (a third of the products) and looks at the largest of a lane's
     // sixteen sums: what the two products with a mid plane can add is bounded by cmarg times the tile's largest
-    // row norm, so where sum + bound stays at or below the entry threshold for every query of the wavefront, no
-    // score of the tile can enter a buffer, now or later (thresholds only rise), and the tile is done.  A tile that
-    // fails the test is only marked.  The marked tiles of a stretch of the sweep are worked off when the stretch
-    // ends: each wavefront takes both planes of its marked tiles straight from the workspace (which the cache
-    // holds), forms all three products and runs the selection.  While tiles are swept, every wavefront does the
-    // same short step and the ring of images keeps them together; while marked tiles are worked off, no wavefront
-    // needs another -- a wavefront with many of them holds the rest up only at the end of the stretch, instead
-    // of at every one of its tiles.  Stretches double from one tile to SEG tiles (the thresholds move fastest
-    // at the start) and stay there.
+    // row norm, so where sum + bound stays at or below the entry threshold for every query of a group of 32, no
+    // score of the tile can enter a buffer, now or later (thresholds only rise), and the tile is done for the group.
+    // A tile that fails the test is only marked.  The marked tiles of a stretch of the sweep are worked off when the
+    // stretch ends: each wavefront takes both planes of its marked tiles straight from the workspace (which the
+    // cache holds), forms all three products and runs the selection.  Stretches double from one tile to SEG tiles
+    // (the thresholds move fastest at the start) and stay there.
+    //
+    // A swept tile is bound by the number of instructions beside its products (operand reads, staging, progress
+    // words: about a hundred, against eight products), and they are the same whether the operands meet 32 queries
+    // or 64.  So half of the wavefronts sweep -- one per SIMD, each for its own group of queries and for the group
+    // of the wavefront NS above it, sixteen products per tile and operand read -- while the other half waits at the
+    // barrier; the marks of the partner's group go back through LDS, and everything else (marked tiles,
+    // compactions, the final stage) is done by all wavefronts, each for its own group, as the latencies of that
+    // work want it.  A sweeping wavefront reads its partner's entry thresholds and coarse margins from LDS and
+    // the partner's hi plane from the query matrix at the start of every stretch.
     constexpr int SEG = MIREC_TOPK_STRETCH;
-    unsigned long long marks = 0ull;  // bit r: tile r of the stretch (the same in all lanes: a pair of scalar registers)
+    unsigned long long marks = 0ull;   // bit r: tile r of the stretch (the same in all lanes: a pair of scalar registers)
+    unsigned long long marks1 = 0ull;  // the same for the partner's group (sweeping wavefronts)
     static_assert(SEG <= 64, "a mark per tile of the stretch in one 64-bit scalar");
-    int dma_next = D < ntile ? D : ntile;  // the images of the tiles below this number have been requested
-    // Wait until the image of tile t is complete and the slot that the next request overwrites is free: everybody
-    // has the operands of the tile that was there in registers.  `seen`: this lane's progress word as read earlier.
+    // Wait until the image of tile t is complete.  `seen`: this lane's progress word as read earlier.
     auto ready = [&](int t, int seen) __attribute__((always_inline)) {
-        const int need = t + need_off;
-        if (__ballot(watcher && seen < need) != 0ull) {
-            while (__ballot(watcher && tk_load_acquire(my_word) < need) != 0ull) __builtin_amdgcn_s_sleep(1);
+        const int need = t + 1;
+        if (__ballot(seen < need) != 0ull) {
+            while (__ballot(tk_load_acquire(my_word) < need) != 0ull) __builtin_amdgcn_s_sleep(1);
         }
     };
     // the sixteen sums of a lane against the entry threshold: true = the tile has to be worked
-    auto test = [&](const f32x16& a, float tn) __attribute__((always_inline)) -> bool {
+    auto test = [&](const f32x16& a, float tn, float cm, float th) __attribute__((always_inline)) -> bool {
         float best = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
         best = fmaxf(best, fmaxf(fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]))));
-        return __ballot(fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr) != 0ull;
+        return __ballot(fmaf(cm, tn, best) + (float)(8 * F + 64) * 2.4e-38f > th) != 0ull;
     };
     // the same in eight instructions (a maximum written in the language costs an extra instruction per input,
     // which quiets signalling NaNs; v_max3_f32 returns the other operands where one is a NaN, as fmaxf does).
-    // Only where the sums are old: the assembler statement hides from the compiler that they come from the
-    // matrix pipe, whose results must not be read too early.
-    auto test_fast = [&](const f32x16& a, float tn) __attribute__((always_inline)) -> bool {
+    // Only where the sums are old -- at least four products issued since the last one into them: the assembler
+    // statement hides from the compiler that they come from the matrix pipe, whose results must not be read too
+    // early.
+    auto test_fast = [&](const f32x16& a, float tn, float cm, float th) __attribute__((always_inline)) -> bool {
         auto max3 = [](float x, float y, float z) __attribute__((always_inline)) -> float {
             float r;
             asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
@@ -726,30 +769,30 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
         const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
         const float best = max3(max3(m0, m1, m2), max3(m3, m4, a[15]), -INFINITY);
-        return __ballot(fmaf(cmarg, tn, best) + (float)(8 * F + 64) * 2.4e-38f > thr) != 0ull;
+        return __ballot(fmaf(cm, tn, best) + (float)(8 * F + 64) * 2.4e-38f > th) != 0ull;
     };
-    auto mark = [&](int rel) __attribute__((always_inline)) { marks |= 1ull << rel; };
-    // One stretch [a, b) of the sweep, software-pipelined by hand: between the eight products of tile t the
-    // wavefront issues the operand reads of tile t + 1, the read of its progress word, and the test of tile
-    // t - 1 -- a matrix instruction keeps the pipe for 32 cycles and the issue port for 8, so what fits into the
-    // gaps is free, and nothing in the loop waits for a latency it has just started.  The loop is bound by the
-    // number of instructions beside the products, so there are no branches in a tile but the rare ones out of it.
-    // (The operand of k-step s is read into the registers that the product of that k-step has just taken its
-    // operand from: one set of operand registers, each read a whole tile ahead of its use.)
+    auto test_old = [&](const f32x16& a, float tn, float cm, float th) __attribute__((always_inline)) -> bool {
+        if constexpr (KS >= 5)
+            return test_fast(a, tn, cm, th);
+        else
+            return test(a, tn, cm, th);
+    };
+    // One stretch [a, b) of the sweep, software-pipelined by hand: the products of tile t for the own group, then
+    // those for the partner's; between them the wavefront issues the operand reads of tile t + 1 (the operand of
+    // k-step s into the registers that the second product of that k-step has just taken its operand from: one set
+    // of operand registers, each read a whole tile ahead of its use), the read of its progress word, and the test
+    // of the sums that are at rest -- the partner's of tile t - 1 under the own products, the own of tile t under
+    // the partner's.  A matrix instruction keeps the pipe for 32 cycles and the issue port for 8, so what fits into
+    // the gaps is free, and nothing in the loop waits for a latency it has just started; there are no branches in
+    // a tile but the rare ones out of it.
     tk_u32x4 ya[KS];
-    f32x16 acc[2];
-    // lane l of register j: the largest row norm of tile 64 j + l of the stretch (a scalar load in the loop would
-    // make every wait for an operand a wait for everything in flight)
-    constexpr int NTN = (SEG + 63) / 64;
+    f32x16 acc0, acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // lane l: the largest row norm of tile l of the stretch (a scalar load in the loop would make every wait for an
+    // operand a wait for everything in flight)
+    constexpr int NTN = 1;
     float tnv[NTN];
     auto tnorm = [&](int rel) __attribute__((always_inline)) -> float {
-        float r = 0.f;
-#pragma unroll
-        for (int j = 0; j < NTN; ++j) {
-            const float v = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tnv[j]), rel & 63));
-            r = (rel >> 6) == j ? v : r;
-        }
-        return r;
+        return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tnv[0]), rel & 63));
     };
     const char* ylane = ybuf + c * L::ROWB + 16 * h;  // this lane's row and half in slot 0
     int fetch_slot = 0;                               // the slot of the tile whose operands are read next
@@ -761,51 +804,110 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     auto fetch_advance = [&]() __attribute__((always_inline)) {
         fetch_slot = fetch_slot + L::IMGB == PD * L::IMGB ? 0 : fetch_slot + L::IMGB;
     };
-    long long* my_progress = reinterpret_cast<long long*>(sync + 2 * w);
-    // parity P: which accumulator takes tile t; NEXT: tile t + 1 belongs to the stretch
-    auto pipelined_tile = [&](int t, int a, int& seen, auto parity, auto has_next) __attribute__((always_inline)) {
-        constexpr int P = decltype(parity)::value;
+    int* my_progress = sync + 8 + w;
+    unsigned char* my_flags = xflag + 128 * (sweeper ? w : 0);
+    // q1, thr1, cm1: the partner group's hi plane, entry thresholds and coarse margins; NEXT: tile t + 1 belongs to
+    // the stretch.  A wavefront alone on its SIMD issues in order, and a matrix instruction that finds the pipe busy
+    // holds up everything behind it: what stands between two products runs under the first of them only as far as it
+    // fits into its 32 cycles, so the tile's other work is cut into pieces of a handful of instructions, one or two to
+    // a gap -- a test in four (five maxima of three, the last three, bound and compare, the mark).
+    auto max3 = [](float x, float y, float z) __attribute__((always_inline)) -> float {
+        float r;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+        return r;
+    };
+    auto swept_tile = [&](int t, int a, int& seen, const tk_u32x4 (&q1)[KS], float thr1, float cm1, auto has_next)
+                          __attribute__((always_inline)) {
         constexpr bool NEXT = decltype(has_next)::value;
-        bool issued = false;
-        if constexpr (NEXT) {
-            ready(t + 1, seen);
-            if (dma_next < ntile) {
-                dma(dma_next++);
-                issued = true;
-            }
-        }
+        constexpr bool PIECES = KS >= 8;  // (narrower operands: the test in one piece, written in the language)
+        constexpr int S_TEST = KS > 4 ? 4 : KS - 1, S_READY = KS > 6 ? 6 : KS - 1;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        bool work_prev = false;
+        bool work0 = false, work1 = false;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, best = 0.f;
+        // (a failed test sets a byte, lane by lane: finding out whether any lane failed, and keeping a mask of the
+        // tiles in scalar registers, took a dozen scalar instructions per tile and group)
+        unsigned char* fl0 = my_flags + (t - a);       // tile t, own group
+        unsigned char* fl1 = my_flags + 64 + (t - a);  // tile t - 1, partner's group: byte 64 + (t - 1 - a) + 1
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            acc[P] = tk_mma(ya[s], qh[s], s == 0 ? zero : acc[P]);
+            acc0 = tk_mma(ya[s], qh[s], s == 0 ? zero : acc0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NEXT) fetch_part(s, s + 1);
-            if (s == (KS > 4 ? 4 : KS - 1) && t > a) work_prev = test_fast(acc[P ^ 1], tnorm(t - 1 - a));
-            if (s == (KS > 5 ? 5 : KS - 1)) seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (NEXT)
+                if (s == 0) seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (PIECES) {
+                // the partner group's sums of tile t - 1 (of nothing, at the first tile of a stretch)
+                if (s == 2) {
+                    m0 = max3(acc1[0], acc1[1], acc1[2]), m1 = max3(acc1[3], acc1[4], acc1[5]);
+                    m2 = max3(acc1[6], acc1[7], acc1[8]), m3 = max3(acc1[9], acc1[10], acc1[11]);
+                    m4 = max3(acc1[12], acc1[13], acc1[14]);
+                }
+                if (s == 3) best = max3(max3(m0, m1, m2), max3(m3, m4, acc1[15]), -INFINITY);
+                if (s == 4) work1 = fmaf(cm1, tnorm(t - 1 - a), best) + (float)(8 * F + 64) * 2.4e-38f > thr1;
+                if (s == 5)
+                    if (work1) *fl1 = 1;
+            } else {
+                if (s == S_TEST) {
+                    if (t > a) work1 = test_old(acc1, tnorm(t - 1 - a), cm1, thr1);
+                    if (work1) marks1 |= 1ull << (t - 1 - a);
+                }
+            }
+            if constexpr (NEXT)
+                if (s == S_READY) ready(t + 1, seen);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (NEXT) fetch_advance();
-        if (work_prev) mark(t - 1 - a);
-        // this wavefront's pieces of the images requested before this tile's have landed, and its operands of
-        // tile t are in registers
-        if (issued) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        static_assert(L::NPW == 2, "the wait above leaves one tile's pieces of this wavefront in flight");
-        if (lane == 0) {
-            const long long v = (long long)(unsigned)(issued ? dma_next - 1 : dma_next) | ((long long)(t + 1) << 32);
-            __hip_atomic_store(my_progress, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            acc1 = tk_mma(ya[s], q1[s], s == 0 ? zero : acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NEXT) fetch_part(s, s + 1);
+            // the operands of tile t are in registers (the last product of the first eight has waited for them);
+            // every lane stores the same word: cheaper than singling one out
+            if (s == 0) __hip_atomic_store(my_progress, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (PIECES) {
+                if (s == 2) {
+                    m0 = max3(acc0[0], acc0[1], acc0[2]), m1 = max3(acc0[3], acc0[4], acc0[5]);
+                    m2 = max3(acc0[6], acc0[7], acc0[8]), m3 = max3(acc0[9], acc0[10], acc0[11]);
+                    m4 = max3(acc0[12], acc0[13], acc0[14]);
+                }
+                if (s == 3) best = max3(max3(m0, m1, m2), max3(m3, m4, acc0[15]), -INFINITY);
+                if (s == 4) work0 = fmaf(cmarg, tnorm(t - a), best) + (float)(8 * F + 64) * 2.4e-38f > thr;
+                if (s == 5)
+                    if (work0) *fl0 = 1;
+            } else {
+                if (s == S_TEST) {
+                    work0 = test_old(acc0, tnorm(t - a), cmarg, thr);
+                    if (work0) marks |= 1ull << (t - a);
+                }
+            }
+            if constexpr (NEXT)
+                if (s == KS - 1) fetch_advance();
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     using T = std::true_type;
     using N = std::false_type;
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
     auto sweep_stretch = [&](int a, int b) __attribute__((always_inline)) {
+        // the partner's group: query slot q + 32 NS
+        tk_u32x4 q1[KS];
+        {
+            const bool pv = ug + 32 * NS < nq;
+            const float* qr = Q + (pv ? ug + 32 * NS : 0) * F + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(qr + 16 * s);
+                f32x4 y = *reinterpret_cast<const f32x4*>(qr + 16 * s + 4);
+                if (!pv) {
+                    x = f32x4{0.f, 0.f, 0.f, 0.f};
+                    y = x;
+                }
+                tk_u32x4 mid;
+                tk_split8(x, y, q1[s], mid);
+            }
+        }
+        float thr1 = xthr[q + 32 * NS], cm1 = xcm[q + 32 * NS];
         int seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ready(a, seen);
-        if (dma_next < ntile && dma_next <= a + D) dma(dma_next++);
         fetch_part(0, KS);
         fetch_advance();
 #pragma unroll
@@ -817,21 +919,17 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         // the loop, where it would be a wait for every image on its way, tile after tile
 #pragma unroll
         for (int j = 0; j < NTN; ++j) asm volatile("" : "+v"(tnv[j]));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(q1[s]));
+        asm volatile("" : "+v"(thr1), "+v"(cm1));
+        if (lane < 32) reinterpret_cast<unsigned*>(my_flags)[lane] = 0u;
         int t = a;
-        for (; t + 2 < b; t += 2) {
-            pipelined_tile(t, a, seen, P0{}, T{});
-            pipelined_tile(t + 1, a, seen, P1{}, T{});
-        }
-        bool work_last;
-        if (t + 1 < b) {
-            pipelined_tile(t, a, seen, P0{}, T{});
-            pipelined_tile(t + 1, a, seen, P1{}, N{});
-            work_last = test(acc[1], tnorm(b - 1 - a));
-        } else {
-            pipelined_tile(t, a, seen, P0{}, N{});
-            work_last = test(acc[0], tnorm(b - 1 - a));
-        }
-        if (work_last) mark(b - 1 - a);
+        for (; t + 1 < b; ++t) swept_tile(t, a, seen, q1, thr1, cm1, T{});
+        swept_tile(t, a, seen, q1, thr1, cm1, N{});
+        if (test(acc1, tnorm(b - 1 - a), cm1, thr1)) marks1 |= 1ull << (b - 1 - a);
+        // byte 64 is the partner group's sums of before the stretch
+        marks |= __ballot(my_flags[lane] != 0);
+        marks1 |= __ballot(lane < 63 && my_flags[65 + (lane < 63 ? lane : 0)] != 0);
     };
     // (The operands of a marked tile come straight from the workspace, from the sections laid out by chunks: the
     // lanes of a load read 1 KiB in a row.  By rows -- each lane its own row, 32 cache lines per instruction -- the
@@ -917,7 +1015,21 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     for (int seg_a = 0; seg_a < ntile;) {
         int seg_b = seg_a == 0 ? 1 : (seg_a < SEG ? 2 * seg_a : seg_a + SEG);
         seg_b = seg_b < ntile ? seg_b : ntile;
-        sweep_stretch(seg_a, seg_b);
+        if (h == 0) xthr[q] = thr;
+        __syncthreads();  // everybody's thresholds are up; the marks of the stretch before have been taken
+        if (sweeper) {
+            sweep_stretch(seg_a, seg_b);
+            if (lane == 0) xmark[w + NS] = marks1;
+            marks1 = 0ull;
+        } else {
+            load_until(seg_b + PD - 1 < ntile ? seg_b + PD - 1 : ntile);
+        }
+        __syncthreads();
+        if (!sweeper) {
+            const unsigned long long m = xmark[w];
+            marks = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m) |
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)) << 32);
+        }
         // the marked tiles in ascending order (the filter is walked forward only)
         if (marks != 0ull) {
             while (marks != 0ull) {
