@@ -376,8 +376,10 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const uint32_t* __restrict__ planes, const float* __restrict__ tile_norm, const uint32_t* __restrict__ ymax_bits,
     const int64_t* __restrict__ mask_indptr, const int32_t* __restrict__ mask_indices,
     const int32_t* __restrict__ block_len, const int32_t* __restrict__ order, int k, int32_t* __restrict__ out_ids,
-    float* __restrict__ out_scores, int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
+    float* __restrict__ out_scores, int32_t* __restrict__ qlist, int32_t* __restrict__ qcount,
+    int32_t* __restrict__ stash_flags, int stash_slots, tk_u32x4* __restrict__ stash) {
     using L = TopkPlanesLds<F, NW, CAP, PD>;
+    static_assert(L::NQ == TOPK_WG_QUERIES, "the workspace is sized for workgroups of this many queries");
     constexpr int KS = F / 16;  // MFMA k-steps
     constexpr int F8 = F / 8;   // 16-byte chunks per plane row
     constexpr int BI = TOPK_BI;
@@ -416,6 +418,16 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     if (h == 0) cnt[q] = 0;
     if (tid < L::SYNC_WORDS) sync[tid] = 0;
     __syncthreads();
+    // A slot of the workspace for this workgroup, for as long as it runs: there are several times as many as
+    // workgroups in flight, so the probe finds a free one at once.
+    if (tid == 0) {
+        int sl = (int)(blockIdx.x % (unsigned)stash_slots);
+        while (atomicCAS(stash_flags + sl, 0, 1) != 0) {
+            sl = sl + 1 == stash_slots ? 0 : sl + 1;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        sync[L::SYNC_WORDS - 1] = sl;
+    }
 
     // B operands: query row ug, factors 16*s + 8*h .. + 7, as two bf16 planes; and the margins of the query
     tk_u32x4 qh[KS], qm[KS];
@@ -695,9 +707,19 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(sync + (w - NS), dma_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    if (!sweeper) load_until(PD - 1 < ntile ? PD - 1 : ntile);
+    __syncthreads();  // the slot number is up
+    // the hi plane of the wavefront's queries, for the sweeping wavefront NS below: k-step s of lane l at chunk
+    // 64 s + l of the wavefront's part of the slot (a load or store of a wavefront is 1 KiB in a row)
+    tk_u32x4* my_stash = stash + ((size_t)sync[L::SYNC_WORDS - 1] * NS + (sweeper ? w : w - NS)) * (64 * KS) + lane;
+    if (!sweeper) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) my_stash[64 * s] = qh[s];
+        load_until(PD - 1 < ntile ? PD - 1 : ntile);
+    }
     if (h == 0) xcm[q] = cmarg;
-    __syncthreads();  // the first tiles are staged, the fill counts and coarse margins are set
+    // the first tiles are staged, the fill counts and coarse margins are set, the hi planes are where the sweeping
+    // wavefronts find them (a barrier of the language: it orders the stores in front of the loads behind it)
+    __syncthreads();
 
     // One candidate: reserve a slot of the query's buffer and fill it; false: the buffer is full.
     auto append = [&](float s, int item) __attribute__((always_inline)) -> bool {
@@ -888,23 +910,10 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     using T = std::true_type;
     using N = std::false_type;
     auto sweep_stretch = [&](int a, int b) __attribute__((always_inline)) {
-        // the partner's group: query slot q + 32 NS
+        // the partner's group (query slot q + 32 NS): its hi plane, as the partner left it
         tk_u32x4 q1[KS];
-        {
-            const bool pv = ug + 32 * NS < nq;
-            const float* qr = Q + (pv ? ug + 32 * NS : 0) * F + 8 * h;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                f32x4 x = *reinterpret_cast<const f32x4*>(qr + 16 * s);
-                f32x4 y = *reinterpret_cast<const f32x4*>(qr + 16 * s + 4);
-                if (!pv) {
-                    x = f32x4{0.f, 0.f, 0.f, 0.f};
-                    y = x;
-                }
-                tk_u32x4 mid;
-                tk_split8(x, y, q1[s], mid);
-            }
-        }
+        for (int s = 0; s < KS; ++s) q1[s] = my_stash[64 * s];
         float thr1 = xthr[q + 32 * NS], cm1 = xcm[q + 32 * NS];
         int seen = __hip_atomic_load(my_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ready(a, seen);
@@ -1043,6 +1052,8 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
         seg_a = seg_b;
     }
 
+    // (every load from the slot has come back: the barrier behind the last sweep waited for them)
+    if (tid == 0) atomicExch(stash_flags + sync[L::SYNC_WORDS - 1], 0);
     // ---- margin set -> exact scores -> the k best, for the 32 queries of the wavefront
     bool over;
     int nfin = tk_compact_all<CAP, NQ, L::LIMIT>(sel_s, sel_i, cnt, q, h, k, marg, thr, over);
@@ -1193,9 +1204,12 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
     int32_t* qlist = reinterpret_cast<int32_t*>(base + lay.qlist_off);
     float* tile_norm = reinterpret_cast<float*>(base + lay.tnorm_off);
     uint32_t* planes = reinterpret_cast<uint32_t*>(base + lay.planes_off);
+    int32_t* stash_flags = reinterpret_cast<int32_t*>(base + lay.flags_off);
+    tk_u32x4* stash = reinterpret_cast<tk_u32x4*>(base + lay.stash_off);
     const int ntile = (int)((ni + TOPK_BI - 1) / TOPK_BI);
 
     MIREC_HIP(hipMemsetAsync(base, 0, 256, stream));
+    MIREC_HIP(hipMemsetAsync(stash_flags, 0, (size_t)lay.stash_slots * 4, stream));
     if (item_order == nullptr && mask_indptr == nullptr) {
         int32_t* bins = reinterpret_cast<int32_t*>(base + lay.bins_off);
         int32_t* made = reinterpret_cast<int32_t*>(base + lay.order_off);
@@ -1215,11 +1229,11 @@ static int launch_topk_planes_cfg(const float* Q, int64_t nq, const float* Y, in
         // the sweep meets positions of the order; its filter is the lists per 32 queries, in positions
         hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD, true>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream,
                            Q, nq, Y, ni, planes, tile_norm, ymax_bits, mask_indptr, mask_blocks, block_len, item_order, k,
-                           out_ids, out_scores, qlist, qcount);
+                           out_ids, out_scores, qlist, qcount, stash_flags, lay.stash_slots, stash);
     } else {
         hipLaunchKernelGGL((topk_planes_kernel<F, NW, CAP, PD, false>), dim3((unsigned)blocks), dim3(64 * NW), L::BYTES, stream,
                            Q, nq, Y, ni, planes, tile_norm, ymax_bits, mask_indptr, mask_indices, nullptr, nullptr, k, out_ids,
-                           out_scores, qlist, qcount);
+                           out_scores, qlist, qcount, stash_flags, lay.stash_slots, stash);
     }
     MIREC_LAUNCH_CHECK();
     // the queries handed over (none, as a rule): the fp32 kernel in list mode, sized for the worst case

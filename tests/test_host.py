@@ -57,8 +57,11 @@ def test_scoring_width_and_topk_workspace_sizes():
     assert [E.scoring_width(f, 20) for f in (5, 17, 20, 40, 64, 100, 128, 130)] == [16, 32, 32, 48, 64, 128, 128, 160]
     assert E.scoring_width(17, 100) == 24 and E.scoring_width(128, 100) == 128
     hot = lib.mirec_topk_workspace_bytes
-    # header, query list, one norm per item tile, bins and items of an in-call sweep order, the two bf16 planes
-    assert hot(1000, 27000, 128, 20) == 256 + 4096 + 3584 + 4096 * 4 + 108032 + 844 * 3 * 32 * 128 * 2
+    # header, query list, one norm per item tile, bins and items of an in-call sweep order, the three images of an
+    # item tile, and per workgroup in flight (4 of 256 queries here, 1024 at most) a flag and 128 rows of a bf16 plane
+    assert hot(1000, 27000, 128, 20) == (256 + 4096 + 3584 + 4096 * 4 + 108032 + 844 * 3 * 32 * 128 * 2
+                                         + 256 + 4 * 128 * 128 * 2)
+    assert hot(10**6, 27000, 128, 20) - hot(10**6 - 256 * 100, 27000, 128, 20) == 4 * 256 * 100  # only the query list
     assert hot(1000, 27000, 128, 25) == 0 and hot(1000, 27000, 160, 20) == 0 and hot(1000, 27000, 24, 20) == 0
     assert hot(0, 27000, 128, 20) == 0 and hot(1000, 0, 128, 20) == 0
 

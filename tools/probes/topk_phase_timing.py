@@ -58,4 +58,5 @@ for mask in (Cui, ordered, None):
           % (v[0] / nw, v[1] / nw, v[1] / nw / ntile, v[2] / nw, v[5] / nw, v[2] / max(v[5], 1), v[3] / nw, v[4] / nw),
           flush=True)
     # (the sweep as every wavefront sees it, the wait at the barriers included; inside the sweeping half:)
-    print("  sweeping wavefronts alone: %.0f cycles per tile" % (v[7] / (nw / 2) / ntile), flush=True)
+    print("  sweeping wavefronts alone: %.0f cycles per tile, %.0f of them in the loop over the tiles"
+          % (v[7] / (nw / 2) / ntile, v[8] / (nw / 2) / ntile), flush=True)
