@@ -548,6 +548,11 @@ __device__ __forceinline__ sm_f32x2 sm_scale_for(float bound) {
 // A server starts a sweep when every solver that still has rows has published, or after this many polls with at
 // least one vector waiting (a bound, so that the loop ends whatever the solvers do; with it reached the sweep
 // serves those that wait -- any split of the vectors over sweeps gives the same results).
+// Units of a server whose sums are built side by side: 1 / 2 / 4 ran the 1 M x 27 k user half-sweep in 6.27 / 6.20 /
+// 6.37 ms (four keep so many sums that fragments of G spill); same bits.
+#ifndef MIREC_SRV_CHAINS
+#define MIREC_SRV_CHAINS 2
+#endif
 #ifndef MIREC_SRV_MAX_POLLS
 #define MIREC_SRV_MAX_POLLS 100000
 #endif
@@ -720,20 +725,32 @@ __device__ __forceinline__ void symv_server(float* smem, const float* __restrict
             b[0][s] = *reinterpret_cast<const sm_u32x4*>(src);
             b[1][s] = *reinterpret_cast<const sm_u32x4*>(src + PLANEB);
         }
+        // (the sums of MIREC_SRV_CHAINS units are built side by side: a matrix instruction that adds to the result of
+        // the one just before it waits for that result, the next unit's does not)
+        constexpr int NCH = MIREC_SRV_CHAINS;
+        static_assert(M::UPS % NCH == 0, "units of a server in groups");
 #pragma unroll
-        for (int j = 0; j < M::UPS; ++j) {
-            const int t = (srv * M::UPS + j) % M::TILES;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < M::UPS; j += NCH) {
+            f32x4 acc[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < M::KSU; ++s) {
                 // smallest products first; mid*mid is below 2^-22 of the term and dropped
-                acc = sm_mma(Ag[j][1][s], b[0][s], acc);
-                acc = sm_mma(Ag[j][0][s], b[1][s], acc);
-                acc = sm_mma(Ag[j][0][s], b[0][s], acc);
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) acc[i] = sm_mma(Ag[j + i][1][s], b[0][s], acc[i]);
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) acc[i] = sm_mma(Ag[j + i][0][s], b[1][s], acc[i]);
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) acc[i] = sm_mma(Ag[j + i][0][s], b[0][s], acc[i]);
             }
             // lane (n, q) holds rows 16t + 4q .. + 3 of G times vector n; only columns that were waiting count
             // (the others were read while their solver may have been writing them)
-            if (pend) *reinterpret_cast<f32x4*>(part + (kp * M::COLS + n) * M::PART_ROW + 16 * t + 4 * q) = acc;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int t = (srv * M::UPS + j + i) % M::TILES;
+                if (pend) *reinterpret_cast<f32x4*>(part + (kp * M::COLS + n) * M::PART_ROW + 16 * t + 4 * q) = acc[i];
+            }
         }
         seen = pubv;
         // the release orders this wavefront's stores before the counts
