@@ -364,16 +364,23 @@ class AlternatingLeastSquares:
         scores float32), best first; ties by ascending item index."""
         if self.user_factors is None or self.item_factors is None:
             raise ValueError("model has not been fitted")
-        if recalculate_user:
-            raise NotImplementedError("recalculate_user=True is not supported")
-        if items is not None:
-            raise NotImplementedError("restricting the candidate set with items= is not supported")
+        if filter_items is not None and items is not None:
+            raise ValueError("Can't specify both filter_items and items")
         scalar = np.isscalar(userid)
-        if scalar and filter_items is None:
+        if scalar and filter_items is None and items is None and not recalculate_user:
             return self._recommend_one(int(userid), user_items, int(N), bool(filter_already_liked_items))
         uids = np.atleast_1d(np.asarray(userid)).astype(np.int64)
         if uids.size and (uids.min() < 0 or uids.max() >= self.user_factors.shape[0]):
             raise IndexError("a userid is out of range")     # checked here: the device gathers without bounds checks
+        if items is not None:
+            items = np.asarray(items, dtype=np.int64).ravel()
+            if items.size == 0 or items.min() < 0 or items.max() >= self.item_factors.shape[0]:
+                raise IndexError("items must name at least one item, all of them in range")
+        if recalculate_user:
+            if user_items is None and self._attached is not None:
+                user_items = self._attached[0][uids]
+            if not sp.isspmatrix_csr(user_items) or user_items.shape[0] != len(uids):
+                raise ValueError("recalculate_user needs user_items: a CSR matrix with 1 row for every user in userids")
         mask = None
         if filter_already_liked_items or filter_items is not None:
             if filter_already_liked_items:
@@ -392,20 +399,71 @@ class AlternatingLeastSquares:
                                        (np.repeat(np.arange(len(uids)), len(fi)), np.tile(fi, len(uids)))),
                                       shape=mask.shape)
                 mask = sp.csr_matrix(mask + extra)
+            if items is not None:
+                # the candidates are the given items, in the given order: the filter is told in their numbering
+                mask = sp.csr_matrix(mask[:, items])
             if not mask.has_sorted_indices:
                 mask = mask.sorted_indices()
         dev = E.require_cuda(self.device)
         with self._lock, torch.cuda.device(dev):
             st = self._serving_state(dev)
             Yd = st.Y
-            Q = st.X.index_select(0, torch.from_numpy(uids).to(dev))
+            if recalculate_user:
+                Q = self._solve_rows(sp.csr_matrix(user_items), self.item_factors, dev, Yd.shape[1])
+            else:
+                Q = st.X.index_select(0, torch.from_numpy(uids).to(dev))
+            if items is not None:
+                Yd = Yd.index_select(0, torch.from_numpy(items).to(dev))
             dmask = None if mask is None else E.DeviceCSR.from_scipy(mask, dev)
             ids, scores = E.topk(Q, Yd, int(N), dmask)
             ids = _hide_filtered(ids, scores, dmask)
             ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+        if items is not None:
+            ids = np.where(ids >= 0, items[np.maximum(ids, 0)], -1).astype(np.int32)
         if scalar:
             return ids[0], scores[0]
         return ids, scores
+
+    def _solve_rows(self, rows: sp.csr_matrix, other_host: np.ndarray, dev: torch.device, width: int) -> torch.Tensor:
+        """Factors for the rows of ``rows`` from scratch, with the other side's factors fixed: per row the exact
+        solution of (Y^T Y + reg I + sum_i (c_i - 1) y_i y_i^T) x = sum_i c_i y_i with the stored values as the
+        confidences c_i -- implicit 0.7.2's ``recalculate_user`` / ``recalculate_item`` (its ``user_factor``,
+        ``np.linalg.solve`` on ``user_linear_equation``), here one half-sweep of the Cholesky solver.  A row
+        without entries gets zeros."""
+        if rows.nnz and float(np.abs(rows.data).min()) < 1.0:
+            raise ValueError("recalculating a factor needs |confidence| >= 1 for every stored entry "
+                             "(smaller confidences can make the row's system indefinite)")
+        rows = sp.csr_matrix(rows, dtype=np.float32)
+        if not rows.has_sorted_indices:
+            rows = rows.sorted_indices()
+        if rows.shape[1] != other_host.shape[0]:
+            raise ValueError("the rows have %d columns, the other side has %d rows of factors"
+                             % (rows.shape[1], other_host.shape[0]))
+        F = E.factor_width(self.factors)          # the width the solvers work at; `width`: what the caller scores at
+        other = E.pad_factors(other_host, F, dev)
+        d = E.DeviceCSR.from_scipy(rows, dev)
+        G = E.gram(other, self.regularization)
+        x = torch.zeros((rows.shape[0], F), dtype=torch.float32, device=dev)
+        E.SweepPlan(d, F, short_max=0).sweep(x, other, G, self.SOLVE_EXACT)
+        out = torch.zeros((rows.shape[0], width), dtype=torch.float32, device=dev)
+        out[:, :self.factors] = x[:, :self.factors]
+        return out
+
+    def recalculate_user(self, userid, user_items) -> np.ndarray:
+        """The factors of the users whose interaction rows are ``user_items`` (one row per entry of ``userid``),
+        solved from scratch against the item factors -- for users the model was not fitted on, or whose history has
+        changed.  ``userid`` only fixes the shape of the result (scalar -> one vector), as in implicit."""
+        dev = E.require_cuda(self.device)
+        with self._lock, torch.cuda.device(dev):
+            x = self._solve_rows(sp.csr_matrix(user_items), self.item_factors, dev, self.factors).cpu().numpy()
+        return x[0] if np.isscalar(userid) else x
+
+    def recalculate_item(self, itemid, item_users) -> np.ndarray:
+        """The same for items: ``item_users`` holds one row of user confidences per entry of ``itemid``."""
+        dev = E.require_cuda(self.device)
+        with self._lock, torch.cuda.device(dev):
+            y = self._solve_rows(sp.csr_matrix(item_users), self.user_factors, dev, self.factors).cpu().numpy()
+        return y[0] if np.isscalar(itemid) else y
 
     def recommend_all(self, user_items=None, N: int = 10, filter_already_liked_items: bool = True,
                       users: Optional[tuple] = None):
@@ -453,10 +511,12 @@ class AlternatingLeastSquares:
                       filter_items=None, items=None):
         """Cosine-nearest items: scores = (Y . y) / |Y_i| / |y|, best first (the
         item itself comes first, as in implicit)."""
-        if recalculate_item or filter_items is not None or items is not None:
-            raise NotImplementedError("only the plain similar_items(itemid, N) form is supported")
+        if filter_items is not None and items is not None:
+            raise ValueError("Can't specify both filter_items and items")
         scalar = np.isscalar(itemid)
         dev = E.require_cuda(self.device)
+        if recalculate_item or filter_items is not None or items is not None:
+            return self._similar_items_general(itemid, int(N), recalculate_item, item_users, filter_items, items, dev)
         if scalar:
             iid = int(itemid)
             if not 0 <= iid < self.item_factors.shape[0]:
@@ -476,6 +536,54 @@ class AlternatingLeastSquares:
             qn = torch.from_numpy(np.ascontiguousarray(norms[iids])).to(dev)
             ids, scores = E.topk(Q, Yd, int(N), None, y_norm=yn, q_norm=qn)
             ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+        if scalar:
+            return ids[0], scores[0]
+        return ids, scores
+
+    def _similar_items_general(self, itemid, N, recalculate_item, item_users, filter_items, items, dev):
+        """``similar_items`` with implicit's optional arguments: the query vector solved again from ``item_users``
+        (its norm with it), ``filter_items`` left out of the answer, or the candidates restricted to ``items``
+        (ids come back in the catalogue's numbering)."""
+        scalar = np.isscalar(itemid)
+        iids = np.atleast_1d(np.asarray(itemid)).astype(np.int64)
+        if iids.size and (iids.min() < 0 or iids.max() >= self.item_factors.shape[0]):
+            raise IndexError("an itemid is out of range")
+        norms = self.item_norms
+        if items is not None:
+            items = np.asarray(items, dtype=np.int64).ravel()
+            if items.size == 0 or items.min() < 0 or items.max() >= self.item_factors.shape[0]:
+                raise IndexError("items must name at least one item, all of them in range")
+        if recalculate_item:
+            if not sp.isspmatrix_csr(item_users) or item_users.shape[0] != len(iids):
+                raise ValueError("recalculate_item needs item_users: a CSR matrix with 1 row for every item in itemid")
+        with self._lock, torch.cuda.device(dev):
+            st = self._serving_state(dev)
+            Yd = st.Y
+            if recalculate_item:
+                Q = self._solve_rows(sp.csr_matrix(item_users), self.user_factors, dev, Yd.shape[1])
+                qn_host = np.linalg.norm(Q[:, :self.factors].cpu().numpy(), axis=-1).astype(np.float32)
+                qn_host[qn_host == 0] = 1e-10
+            else:
+                Q = Yd.index_select(0, torch.from_numpy(iids).to(dev))
+                qn_host = np.ascontiguousarray(norms[iids])
+            yn = torch.from_numpy(norms if items is None else np.ascontiguousarray(norms[items])).to(dev)
+            if items is not None:
+                Yd = Yd.index_select(0, torch.from_numpy(items).to(dev))
+            dmask = None
+            if filter_items is not None:
+                fi = np.unique(np.asarray(filter_items, dtype=np.int64))
+                fi = fi[(fi >= 0) & (fi < Yd.shape[0])]
+                m = sp.csr_matrix((np.ones(len(fi) * len(iids), dtype=np.float32),
+                                   (np.repeat(np.arange(len(iids)), len(fi)), np.tile(fi, len(iids)))),
+                                  shape=(len(iids), Yd.shape[0]))
+                m.sort_indices()
+                dmask = E.DeviceCSR.from_scipy(m, dev)
+            ids, scores = E.topk(Q.contiguous(), Yd.contiguous(), N, dmask, y_norm=yn,
+                                 q_norm=torch.from_numpy(qn_host).to(dev))
+            ids = _hide_filtered(ids, scores, dmask)
+            ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+        if items is not None:
+            ids = np.where(ids >= 0, items[np.maximum(ids, 0)], -1).astype(np.int32)
         if scalar:
             return ids[0], scores[0]
         return ids, scores

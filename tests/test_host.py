@@ -390,3 +390,20 @@ print("ok")
     # real model object instead of the mock the same save / load is exercised by this suite's own tests.
     assert "5 passed" in res.stdout and "1 failed" in res.stdout, res.stdout + res.stderr
     assert "test_save_model" in res.stdout and "PicklingError" in res.stdout, res.stdout + res.stderr
+
+
+def test_optional_arguments_are_checked_before_any_device_call():
+    """``items`` together with ``filter_items`` is refused as implicit refuses it, an item outside the catalogue
+    too -- on the host, before the model asks for a device."""
+    model = AlternatingLeastSquares(factors=4)
+    model.user_factors = np.ones((3, 4), dtype=np.float32)
+    model.item_factors = np.ones((5, 4), dtype=np.float32)
+    row = sp.csr_matrix(np.array([[1, 0, 0, 1, 0]], dtype=np.float32))
+    with pytest.raises(ValueError, match="both filter_items and items"):
+        model.recommend(0, row, N=2, items=[1, 2], filter_items=[3])
+    with pytest.raises(ValueError, match="both filter_items and items"):
+        model.similar_items(0, N=2, items=[1, 2], filter_items=[3])
+    with pytest.raises(IndexError):
+        model.recommend(0, row, N=2, items=[1, 5])
+    with pytest.raises(ValueError, match="recalculate_user needs user_items"):
+        model.recommend(0, None, N=2, recalculate_user=True)
