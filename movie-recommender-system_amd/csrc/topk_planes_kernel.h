@@ -259,6 +259,11 @@ __device__ __forceinline__ void tk_wait_all(const int* p, int need, int lane) {
 #ifndef MIREC_TOPK_STRETCH
 #define MIREC_TOPK_STRETCH 64
 #endif
+// Tiles at the start of the sweep that every wavefront works without testing them first (a power of two): 0 / 8 / 16 /
+// 32 / 64 ran the 1 M x 27 k pass in 9.17 / 9.22 / 9.08 / 8.97 / 9.15 ms.
+#ifndef MIREC_TOPK_EARLY
+#define MIREC_TOPK_EARLY 32
+#endif
 
 template <int F, int NW, int CAP, int PD>
 struct TopkPlanesLds {
@@ -415,8 +420,13 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     const int64_t ug = (int64_t)blockIdx.x * NQ + q;
     const bool uv = ug < nq;
 
+    // The first tiles are not swept (further down): the ring, and the counts of tiles in the progress words, start
+    // behind them.
+    constexpr int EARLY = MIREC_TOPK_EARLY;
+    static_assert(EARLY >= 0 && (EARLY & (EARLY - 1)) == 0 && EARLY <= MIREC_TOPK_STRETCH, "whole stretches, doubling");
+    const int t_early = EARLY < ntile ? EARLY : ntile;
     if (h == 0) cnt[q] = 0;
-    if (tid < L::SYNC_WORDS) sync[tid] = 0;
+    if (tid < L::SYNC_WORDS) sync[tid] = t_early;
     __syncthreads();
     // A slot of the workspace for this workgroup, for as long as it runs: there are several times as many as
     // workgroups in flight, so the probe finds a free one at once.
@@ -687,7 +697,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     // The loading wavefronts' side of the ring: request the images of the tiles below `lim`, each when every sweeping
     // wavefront has taken its operands of the tile whose slot it overwrites, D tiles on their way at a time.  The
     // progress word says what has landed (loads complete in order: all but the newest D - 1 requests, after the wait).
-    int dma_next = 0;  // the images of the tiles below this number have been requested
+    int dma_next = t_early;  // the images of the tiles below this number have been requested (or are not needed)
     const int* done_word = sync + 8 + (lane < NS ? lane : 0);
     auto load_until = [&](int lim) __attribute__((always_inline)) {
         int flying = 0;
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     if (!sweeper) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) my_stash[64 * s] = qh[s];
-        load_until(PD - 1 < ntile ? PD - 1 : ntile);
+        load_until(t_early + PD - 1 < ntile ? t_early + PD - 1 : ntile);
     }
     if (h == 0) xcm[q] = cmarg;
     // the first tiles are staged, the fill counts and coarse margins are set, the hi planes are where the sweeping
@@ -1024,20 +1034,28 @@ __global__ __launch_bounds__(64 * NW) void topk_planes_kernel(
     for (int seg_a = 0; seg_a < ntile;) {
         int seg_b = seg_a == 0 ? 1 : (seg_a < SEG ? 2 * seg_a : seg_a + SEG);
         seg_b = seg_b < ntile ? seg_b : ntile;
-        if (h == 0) xthr[q] = thr;
-        __syncthreads();  // everybody's thresholds are up; the marks of the stretch before have been taken
-        if (sweeper) {
-            sweep_stretch(seg_a, seg_b);
-            if (lane == 0) xmark[w + NS] = marks1;
-            marks1 = 0ull;
+        if (seg_a < t_early) {
+            // The first tiles hold the items that most queries score highest (that is what the order of the sweep is
+            // for) and the thresholds start from nothing: nearly every one of them would be marked by every group.
+            // They are not swept: every wavefront works them, stretch by stretch as below, without a barrier.
+            seg_b = seg_b < t_early ? seg_b : t_early;
+            marks = seg_b - seg_a >= 64 ? ~0ull : (1ull << (seg_b - seg_a)) - 1ull;
         } else {
-            load_until(seg_b + PD - 1 < ntile ? seg_b + PD - 1 : ntile);
-        }
-        __syncthreads();
-        if (!sweeper) {
-            const unsigned long long m = xmark[w];
-            marks = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m) |
-                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)) << 32);
+            if (h == 0) xthr[q] = thr;
+            __syncthreads();  // everybody's thresholds are up; the marks of the stretch before have been taken
+            if (sweeper) {
+                sweep_stretch(seg_a, seg_b);
+                if (lane == 0) xmark[w + NS] = marks1;
+                marks1 = 0ull;
+            } else {
+                load_until(seg_b + PD - 1 < ntile ? seg_b + PD - 1 : ntile);
+            }
+            __syncthreads();
+            if (!sweeper) {
+                const unsigned long long m = xmark[w];
+                marks = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m) |
+                        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)) << 32);
+            }
         }
         // the marked tiles in ascending order (the filter is walked forward only)
         if (marks != 0ull) {

@@ -106,12 +106,12 @@ rep("""                }
     for (int seg_a = 0; seg_a < ntile;) {
         const unsigned long long s0 = TKS_T();
 """)
-rep("""        if (sweeper) {
-            sweep_stretch(seg_a, seg_b);
-""","""        if (sweeper) {
-            const unsigned long long ss = TKS_T();
-            sweep_stretch(seg_a, seg_b);
-            TKS_ADD(7, TKS_T() - ss);
+rep("""            if (sweeper) {
+                sweep_stretch(seg_a, seg_b);
+""","""            if (sweeper) {
+                const unsigned long long ss = TKS_T();
+                sweep_stretch(seg_a, seg_b);
+                TKS_ADD(7, TKS_T() - ss);
 """)
 rep("""        // the marked tiles in ascending order (the filter is walked forward only)
         if (marks != 0ull) {
