@@ -32,6 +32,29 @@ __global__ __launch_bounds__(256) void order_count_kernel(const int32_t* __restr
     }
 }
 
+// The same through a histogram per workgroup in LDS (catalogues of up to ORDER_COUNT_LDS items): the popular items,
+// which every workgroup meets thousands of times, cost an LDS atomic each time and one global atomic per workgroup.
+constexpr int ORDER_COUNT_LDS = 36864;  // words of LDS (144 KB)
+
+__global__ __launch_bounds__(1024) void order_count_lds_kernel(const int32_t* __restrict__ indices, int64_t nnz, int ni,
+                                                               int32_t* __restrict__ count) {
+    extern __shared__ uint32_t order_lds[];
+    int32_t* hist = reinterpret_cast<int32_t*>(order_lds);
+    for (int t = threadIdx.x; t < ni; t += 1024) hist[t] = 0;
+    __syncthreads();
+    const int64_t per = (nnz + gridDim.x - 1) / gridDim.x;
+    const int64_t e0 = (int64_t)blockIdx.x * per, e1 = e0 + per < nnz ? e0 + per : nnz;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
+        const int i = indices[e];
+        if (i >= 0 && i < ni) atomicAdd(hist + i, 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ni; t += 1024) {
+        const int v = hist[t];
+        if (v != 0) atomicAdd(count + t, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void order_rank_kernel(const int32_t* __restrict__ count, int ni,
                                                          int32_t* __restrict__ item_order,
                                                          int32_t* __restrict__ position) {
@@ -157,7 +180,24 @@ extern "C" int mirec_topk_order_build(const int64_t* mask_indptr, const int32_t*
     int32_t* count = static_cast<int32_t*>(ws);
     int32_t* position = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + part);
     MIREC_HIP(hipMemsetAsync(count, 0, (size_t)ni * 4, stream));
-    if (nnz > 0) {
+    static OncePerDevice once;
+    bool* attr_done = once.slot();
+    MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
+    if (!*attr_done) {
+        MIREC_HIP(hipFuncSetAttribute((const void*)order_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      ORDER_RANGE * 4));
+        MIREC_HIP(hipFuncSetAttribute((const void*)order_count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      ORDER_COUNT_LDS * 4));
+        *attr_done = true;
+    }
+    if (nnz > 0 && ni <= ORDER_COUNT_LDS && nnz >= 65536) {
+        // a workgroup per CU: each takes a contiguous share of the entries
+        const int64_t share = (nnz + 255) / 256;
+        const unsigned blocks = (unsigned)((nnz + share - 1) / share);
+        hipLaunchKernelGGL(order_count_lds_kernel, dim3(blocks), dim3(1024), (size_t)ni * 4, stream, mask_indices, nnz,
+                           (int)ni, count);
+        MIREC_LAUNCH_CHECK();
+    } else if (nnz > 0) {
         const int64_t blocks = (nnz + 255) / 256;
         hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
                            mask_indices, nnz, (int)ni, count);
@@ -168,14 +208,6 @@ extern "C" int mirec_topk_order_build(const int64_t* mask_indptr, const int32_t*
     MIREC_LAUNCH_CHECK();
     if (nrows > 0) {
         const size_t lds = (size_t)(ni < ORDER_RANGE ? ni : ORDER_RANGE) * 4;
-        static OncePerDevice once;
-        bool* attr_done = once.slot();
-        MIREC_REQUIRE(attr_done != nullptr, MIREC_E_HIP, "cannot read the current device ordinal (or it is >= %d)", kMaxDevices);
-        if (!*attr_done) {
-            MIREC_HIP(hipFuncSetAttribute((const void*)order_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          ORDER_RANGE * 4));
-            *attr_done = true;
-        }
         const int64_t nblk = (nrows + 31) / 32;
         hipLaunchKernelGGL(order_blocks_kernel, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), lds, stream,
                            mask_indptr, mask_indices, nrows, (int)ni, position, reinterpret_cast<int2*>(mask_blocks),

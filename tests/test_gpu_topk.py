@@ -159,9 +159,18 @@ def test_sweep_order_build_matches_host_arithmetic(dev):
     rng = np.random.default_rng(5)
     cases = [(1, [1, 0, 1]), (70, [0, 1, 63, 64, 65, 70, 3]), (3000, [0, 700, 64, 3000, 1, 129, 5, 0] + [0] * 40 + [17]),
              (27001, list(rng.integers(0, 200, size=300)) + [27001, 0, 2048]),
-             (70000, list(rng.integers(0, 90, size=100)) + [40000])]
+             (70000, list(rng.integers(0, 90, size=100)) + [40000]),
+             # enough entries for the counting pass that keeps a histogram per workgroup in LDS (a skewed catalogue:
+             # the first items in nearly every row), and one item more than that histogram holds
+             (20000, list(rng.integers(100, 400, size=500))), (36864, list(rng.integers(100, 300, size=400))),
+             (36865, list(rng.integers(100, 300, size=400)))]
     for ni, lens in cases:
-        rows = [np.sort(rng.choice(ni, size=n, replace=False)).astype(np.int32) for n in lens]
+        if len(lens) >= 400:   # popular head: half of a row's items among the first 50
+            rows = [np.unique(np.concatenate([rng.choice(50, size=min(n // 2, 50), replace=False),
+                                              rng.choice(ni, size=n - n // 2, replace=False)])).astype(np.int32)
+                    for n in lens]
+        else:
+            rows = [np.sort(rng.choice(ni, size=n, replace=False)).astype(np.int32) for n in lens]
         indptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
         indices = np.concatenate(rows).astype(np.int32)
         m = E.DeviceCSR(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
