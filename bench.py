@@ -502,10 +502,11 @@ def main():
             m.build_order()
         torch.cuda.synchronize()
         extra["top20_order_build_ms"] = (time.perf_counter() - t0) * 1e3
-        if jobs:
-            q0, m0 = jobs[0]
-            nw = min(4096, q0.shape[0])
-            E.topk(q0[:nw], Ys, args.topk, m0.rows(0, nw), path="sweep")
+        # one untimed pass first, as the iterations have theirs: code objects loaded, and the output and workspace
+        # blocks (220 MB at the default size) in torch's caching allocator instead of a fresh device allocation inside
+        # the first timed pass
+        outs = [E.topk(Q, Ys, args.topk, m) for Q, m in jobs]
+        del outs
         barrier()
         t0 = time.perf_counter()
         reps = 2
