@@ -478,19 +478,20 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
 // On the vector ALU a product costs F*F/64 fused multiply-adds per lane and a read of all of G from LDS, per
 // row; with the gathers hidden that was a third of the kernel.  A matrix-vector product does not fill a matrix
 // instruction, several of them do.  The workgroup therefore has two kinds of wavefronts:
-//   NS = 10 solvers   each with a row of its own, through the same passes as above, but where the vector
+//   NS solvers        each with a row of its own, through the same passes as above, but where the vector
 //                     kernel multiplies by G they PUBLISH the vector -- scaled by a power of two and split
 //                     into two fp16 planes (v = hi + mid to 22 bits, as the explicit-Gram kernel splits its
 //                     rows) into their row of an LDS image, then a sequence number -- run the pass over the
 //                     gathered rows (the product is not needed before its end) and COLLECT the product;
-//   2 servers         each holding half of G as scaled fp16 fragments in registers.  A server polls the
+//   NSRV servers      each holding its share of G as scaled fp16 fragments in registers.  A server polls the
 //                     sequence numbers, and once the vectors wait evaluates its bands of G times all of
 //                     them with v_mfma_f32_16x16x32_f16 (three plane products per k step, the smallest
 //                     first), stores the columns that were waiting and counts them done.
 // Nobody waits at a barrier: a solver waits only for its own product, which the servers evaluate while it is
 // busy with its pass, so solvers keep hiding each other's memory latency as before.  A column of a product
 // depends on its vector only, so a row's result does not depend on what else was in flight.
-// With G out of LDS and twelve wavefronts of 168 registers, a solver keeps the first 16 * RS gathered rows of
+// Width 128: ten solvers and two servers, twelve wavefronts of 168 registers; width 64: twelve solvers and four
+// servers, sixteen wavefronts of 128 registers.  With G out of LDS a solver keeps the first 16 * RS gathered rows of
 // its CSR row in registers and the next CAP in LDS for all four passes: rows of up to 16 * RS + CAP entries are
 // gathered once.  Measured on the 1 M x 27 k user half-sweep (F = 128): RS = 1 6.17 ms, RS = 2 7.0 ms (the
 // second set of registers spills), sixteen wavefronts of 128 registers with bf16 planes and no rows in
@@ -533,11 +534,24 @@ __device__ __forceinline__ sm_f32x2 sm_scale_for(float bound) {
 #ifndef MIREC_SHORT_RS
 #define MIREC_SHORT_RS 1
 #endif
-// Wavefronts of the workgroup (two of them servers).  The kernel's rate follows the number of solvers, not the
-// number of gathered rows they can keep on chip: 8 wavefronts of 256 registers with 60 / 92 / 108 rows on chip
-// (RS = 1 / 3 / 4) ran the 1 M x 27 k user half-sweep in 7.9 / 7.5 / 7.7 ms, 10 wavefronts in 6.5 ms, 12 in 6.2 ms.
+// Wavefronts of the workgroup and how many of them are servers, for width 128.  The kernel's rate follows the
+// number of solvers, not the number of gathered rows they can keep on chip: 8 wavefronts of 256 registers with
+// 60 / 92 / 108 rows on chip (RS = 1 / 3 / 4) ran the 1 M x 27 k user half-sweep in 7.9 / 7.5 / 7.7 ms, 10
+// wavefronts in 6.5 ms, 12 in 6.2 ms.  Sixteen (four per SIMD, 128 registers: four servers with a quarter of G
+// each) have no room for the register-resident rows: 8.1 ms with them spilled, 6.2 ms without them.
 #ifndef MIREC_SHORT_NW
 #define MIREC_SHORT_NW 12
+#endif
+#ifndef MIREC_SHORT_NSRV
+#define MIREC_SHORT_NSRV 2
+#endif
+// The same for width 64, where a solver needs 116 registers: sixteen wavefronts, twelve of them solvers, ran the
+// 1 M x 27 k user half-sweep in 4.01 ms against the 4.37 ms of twelve and ten; same bits.
+#ifndef MIREC_SHORT_NW64
+#define MIREC_SHORT_NW64 16
+#endif
+#ifndef MIREC_SHORT_NSRV64
+#define MIREC_SHORT_NSRV64 4
 #endif
 // A server sweeps when this many vectors wait (or every solver that still has rows has published).  Smaller
 // batches shorten the first publisher's wait and lengthen everybody else's: 3 / 5 / 7 / 9 gave 6.5 / 6.9 / 7.0 /
@@ -561,8 +575,9 @@ template <int NT>
 struct MfmaShort {
     static_assert(NT == 2 || NT == 4, "matrix-core G v: widths 64 and 128");
     static constexpr int F = 32 * NT;
-    static constexpr int NW = MIREC_SHORT_NW;   // wavefronts of the workgroup: three per SIMD, 168 registers each
-    static constexpr int NSRV = 2;              // servers (the last wavefronts)
+    static constexpr int NW = NT == 2 ? MIREC_SHORT_NW64 : MIREC_SHORT_NW;        // wavefronts of the workgroup
+    static constexpr int NSRV = NT == 2 ? MIREC_SHORT_NSRV64 : MIREC_SHORT_NSRV;  // servers (the last wavefronts)
+    static_assert(NW % 4 == 0 && NW <= 16, "whole wavefronts per SIMD, at most 1024 lanes");
     static constexpr int NS = NW - NSRV;        // solvers
     static constexpr int COLS = 16;             // columns of a matrix instruction (NS of them used)
     static constexpr int RS = MIREC_SHORT_RS;   // steps of a CSR row whose gathered rows stay in registers
@@ -797,7 +812,7 @@ __global__ __launch_bounds__(64 * MfmaShort<NT>::NW) void als_short_mfma_kernel(
         const int n = (int)(indptr[row + 1] - rs);
         float* xg = X + row * F + c * NT;
         float x[NT], rr[NT], p[NT], Ap[NT], acc[NT];
-        float R[RS][GV][NT];  // the first RS * 16 gathered rows of this CSR row (8 per half-wave and step)
+        float R[RS > 0 ? RS : 1][GV][NT];  // the first RS * 16 gathered rows of this CSR row (8 per half-wave and step)
         if (n == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) x[t] = 0.f;

@@ -1,6 +1,6 @@
 """Time the matrix-free user half-sweep of one build of the library and print a digest of its result.
 
-usage: als_short_variants.py <path to libmirec.so> [users items mean_degree]
+usage: als_short_variants.py <path to libmirec.so> [users items mean_degree [width]]
 Builds of the kernel that differ only in how rows are mapped to wavefronts and where gathered rows are kept
 must print the same digest: the arithmetic of a row does not depend on either.
 """
@@ -17,7 +17,7 @@ _lib.load(sys.argv[1])
 from movie_recommender_system_amd import engine as E, synth  # noqa: E402
 
 U, I, deg = (int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (1_000_000, 27_000, 50.0)
-f = 128
+f = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 dev = torch.device("cuda", 0)
 indptr, indices, data = synth.interactions_torch(42, U, I, deg, dev)
 Cui = E.DeviceCSR(indptr, indices, data * 40.0, (U, I))
