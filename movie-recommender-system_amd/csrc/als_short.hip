@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64 * ShortWaves<NT>::SW) void als_short_kernel(
 // Nobody waits at a barrier: a solver waits only for its own product, which the servers evaluate while it is
 // busy with its pass, so solvers keep hiding each other's memory latency as before.  A column of a product
 // depends on its vector only, so a row's result does not depend on what else was in flight.
-// Width 128: ten solvers and two servers, twelve wavefronts of 168 registers; width 64: twelve solvers and four
+// Width 128: ten solvers and two servers, twelve wavefronts of 168 registers; width 64: fourteen solvers and two
 // servers, sixteen wavefronts of 128 registers.  With G out of LDS a solver keeps the first 16 * RS gathered rows of
 // its CSR row in registers and the next CAP in LDS for all four passes: rows of up to 16 * RS + CAP entries are
 // gathered once.  Measured on the 1 M x 27 k user half-sweep (F = 128): RS = 1 6.17 ms, RS = 2 7.0 ms (the
@@ -545,13 +545,14 @@ __device__ __forceinline__ sm_f32x2 sm_scale_for(float bound) {
 #ifndef MIREC_SHORT_NSRV
 #define MIREC_SHORT_NSRV 2
 #endif
-// The same for width 64, where a solver needs 116 registers: sixteen wavefronts, twelve of them solvers, ran the
-// 1 M x 27 k user half-sweep in 4.01 ms against the 4.37 ms of twelve and ten; same bits.
+// The same for width 64, where a solver needs 116 registers and half of G is 32: sixteen wavefronts ran the
+// 1 M x 27 k user half-sweep in 4.01 ms with twelve solvers and four servers, 3.95 ms with fourteen and two, against
+// the 4.37 ms of twelve wavefronts (ten solvers); same bits.
 #ifndef MIREC_SHORT_NW64
 #define MIREC_SHORT_NW64 16
 #endif
 #ifndef MIREC_SHORT_NSRV64
-#define MIREC_SHORT_NSRV64 4
+#define MIREC_SHORT_NSRV64 2
 #endif
 // A server sweeps when this many vectors wait (or every solver that still has rows has published).  Smaller
 // batches shorten the first publisher's wait and lengthen everybody else's: 3 / 5 / 7 / 9 gave 6.5 / 6.9 / 7.0 /
