@@ -105,7 +105,6 @@ __device__ __forceinline__ float dpp_mov(float v) {
 }
 constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int DPP_ROR4 = 0x124;        // rotate within a row by 4 lanes
 constexpr int DPP_ROR8 = 0x128;        // rotate within a row by 8 lanes (= lane ^ 8)
 constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i within groups of 8
 
@@ -121,11 +120,14 @@ __device__ __forceinline__ float swap32_sum(float a) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// Sum over the 32 lanes of a half-wave (all lanes get the result).
+// Sum over the 32 lanes of a half-wave; all lanes get the result, and the SAME BITS: every stage pairs two lanes
+// that add each other's value, so all lanes build one tree.  (A rotation by four lanes in place of the mirror gives
+// the quads of a row two different trees, sums that differ in the last bit from lane to lane, and with them lanes
+// that disagree about a threshold the sum is compared with -- the exponent of a vector's norm, once in ~1e8 rows.)
 __device__ __forceinline__ float half_sum(float v) {
     v += dpp_mov<DPP_XOR1>(v);
     v += dpp_mov<DPP_XOR2>(v);
-    v += dpp_mov<DPP_ROR4>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);  // quads are uniform by now: lane 7 - i stands for lane i ^ 4
     v += dpp_mov<DPP_ROR8>(v);
     return swap16_sum(v, v);
 }
@@ -632,7 +634,8 @@ __device__ __forceinline__ float symv_publish(float* smem, const float (&v)[NT],
     using M = MfmaShort<NT>;
     char* vpl = reinterpret_cast<char*>(smem + M::VPL);
     constexpr int PLANEB = M::PLANE_FLOATS * 4;
-    const sm_f32x2 sc = sm_scale_for(bound);
+    // one scale per vector: the servers' sums mix all columns, so every lane must scale by the same power of two
+    const sm_f32x2 sc = sm_scale_for(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bound))));
     // lane c holds columns c*NT .. c*NT + NT-1; the two halves hold the same values
     if (h == 0) {
         if constexpr (NT == 4) {
